@@ -1,0 +1,222 @@
+/* ssunet_hip.h -- C-ABI of the MI355X (gfx950) hot-path library for ssUnet-GAN training.
+ *
+ * The reference (ideafisher/ssUnet-GAN) is pure Python on stock PyTorch ops; it has no FFI
+ * layer.  The drop-in boundary a maintainer sees is the Python nn.Module / train() surface
+ * (the modules under ssunet-gan_amd/ mirror scripts/); THIS header is the build-defined C-ABI one
+ * level below it: one entry point per stock torch op the reference's hot
+ * path dispatches.  Each entry cites the reference call site(s) whose torch op it replaces
+ * (paths relative to the reference's scripts/).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless noted;
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*) and returns at once;
+ *   - return value: 0 = ok, otherwise a negative SSG_E* code or a positive hipError_t;
+ *     ssg_last_error() returns a thread-local message.  Nothing throws across the ABI;
+ *   - the library allocates nothing and keeps no state between calls: callers own all
+ *     buffers including workspaces (sizes via the *_workspace_bytes helpers);
+ *   - activations are fp32 "NHWC with pixel stride": element (n,y,x,c) of a tensor with
+ *     H x W pixels lives at ((n*H + y)*W + x)*ld + c, ld >= C, ld % 4 == 0, 16-B aligned.
+ */
+#ifndef SSUNET_HIP_H
+#define SSUNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSG_OK 0
+#define SSG_EINVAL (-1)   /* bad argument / unsupported shape */
+#define SSG_EALIGN (-2)   /* pointer or stride alignment */
+
+#define SSG_ACT_NONE 0
+#define SSG_ACT_RELU 1
+#define SSG_ACT_LRELU 2
+
+#define SSG_MAX_TAPS 9
+
+const char* ssg_last_error(void);
+int ssg_abi_version(void);
+
+/* ------------------------------------------------------------------ convolution (MFMA)
+ * Implicit-GEMM convolution, fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
+ * Replaces F.conv2d forward and its input-gradient at: archs.py:210,212,218 (BasicBlock
+ * 3x3 + 1x1 shortcut), archs.py:593-615 (1x1 heads, final), normalization.py:90-96 (SPADE
+ * 3x3), models_seg_gan.py:37-39 (discriminator 3x3 s1/s2), models_seg_gan.py:281-283
+ * (fc1/fc2 as 1x1 on a 1x1 grid).  torch.cat at archs.py:651-667 is absorbed by the
+ * second input pointer.
+ *
+ * One launch computes, for every pixel (n,gy,gx) of a GH x GW grid and every co < Cout:
+ *   acc = sum_t sum_c  in[n, gy*in_sy + dy[t], gx*in_sx + dx[t], c] * w[co, k(t,c)]
+ * (out-of-image taps read 0), then  v = acc (+bias[co]) (+res[pixel,co]) -> act -> out at
+ * pixel (gy*out_sy + out_oy, gx*out_sx + out_ox) of an OH x OW image.  `in` is the
+ * channel-concatenation of in1 (C1 channels) and in2 (C2 channels, may be NULL/0).
+ * Forward conv, stride-1 dgrad (taps mirrored) and stride-2 dgrad (4 parity launches)
+ * are all instances of this.
+ *
+ * Weight operand `w` is a packed matrix [Cout][Kp] (row stride Kp floats, Kp % 16 == 0)
+ * produced by ssg_pack_weights, whose K order must match `kmode`:
+ *   kmode 0 (requires Cin % 16 == 0): k = (c/16)*ntaps*16 + t*16 + c%16
+ *   kmode 1 (Cin % 4 == 0)          : k = t*Cin + c, zero padded to Kp
+ */
+typedef struct {
+  const float* in1; const float* in2;
+  int C1, C2, ld1, ld2;
+  int N, H, W;              /* input image size */
+  const float* w; int Kp; int kmode;
+  const float* bias;        /* [Cout] or NULL */
+  const float* res; int ldr;/* residual, indexed like out, or NULL */
+  float* out; int Cout, ldo;
+  int GH, GW;               /* pixel grid of this launch */
+  int OH, OW;               /* output image size */
+  int in_sy, in_sx, out_sy, out_sx, out_oy, out_ox;
+  int ntaps; int dy[SSG_MAX_TAPS]; int dx[SSG_MAX_TAPS];   /* each in [-2, 5] */
+  int act; float slope;
+  float* bnpart;            /* optional [mtiles][2][Cout] per-tile (sum, sumsq) of acc+bias; NULL = off */
+} ssg_conv_desc;
+
+int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream);
+/* number of M-tiles the launch above uses (rows of bnpart) */
+int ssg_conv2d_igemm_mtiles(const ssg_conv_desc* d);
+
+/* Weight packing from the reference's OIHW parameter layout [O][I][KH][KW] (the
+ * state_dict layout of nn.Conv2d, archs.py:210 etc.) into the [R][Kp] operand above.
+ *   transpose = 0: rows R = O, reduce over I  (forward)
+ *   transpose = 1: rows R = I, reduce over O  (input gradient)
+ * tap t reads kernel position (ky[t], kx[t]).  `Cred_pad` is the reduced-channel count
+ * rounded up to a multiple of 4 (pad channels get zero weights). */
+int ssg_pack_weights_f32(const float* w_oihw, int O, int I, int KH, int KW,
+                         int transpose, int ntaps, const int* ky, const int* kx,
+                         int kmode, int Cred_pad, int Kp, float* out, void* stream);
+
+/* Weight gradient (replaces conv2d's weight-grad at the same call sites).
+ *   dw[co, c, ky[t], kx[t]] = sum_{n,gy,gx} dout[n,gy,gx,co] * in[n, gy*in_sy+dy[t], gx*in_sx+dx[t], c]
+ * Two deterministic stages: split-K partial slabs into `ws`, then an ordered reduce that
+ * writes the OIHW gradient (only c < Cin_real channels; pad channels are dropped).
+ * The bias gradient is ssg_channel_sum_f32 over dout. */
+typedef struct {
+  const float* in1; const float* in2; int C1, C2, ld1, ld2;
+  int N, H, W;
+  const float* dout; int Cout, ldd; int GH, GW;
+  int in_sy, in_sx;
+  int ntaps; int dy[SSG_MAX_TAPS]; int dx[SSG_MAX_TAPS]; int ky[SSG_MAX_TAPS]; int kx[SSG_MAX_TAPS];
+  int KH, KW, Cin_real;
+  float* dw_oihw;           /* [Cout][Cin_real][KH][KW] */
+  float* ws; int64_t ws_bytes;
+} ssg_wgrad_desc;
+
+int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d);
+int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ layout helpers
+ * NCHW (the reference's layout at the boundary: dataset.py:144 tensors, G logits) <->
+ * internal NHWC-with-stride.  Pad channels [C, ld) are written as 0. */
+int ssg_nchw_to_nhwc_f32(const float* src, int N, int C, int H, int W, float* dst, int ld, void* stream);
+int ssg_nhwc_to_nchw_f32(const float* src, int ld, int N, int C, int H, int W, float* dst, void* stream);
+
+/* ------------------------------------------------------------------ batch norm (HBM-bound)
+ * Training-mode BatchNorm2d (archs.py:211,213; models_seg_gan.py:43), eps/momentum as the
+ * module holds them.  Split so a cross-rank all-reduce of the partial sums (sync-BN,
+ * batchnorm.py:63-64,104-107) fits between stage 1 and stage 2.
+ *   stage 1: sums[0:C] = sum_p x[p,c], sums[C:2C] = sum_p x[p,c]^2  (fp64, deterministic)
+ *   stage 2: mean, invstd; scale = w*invstd, shift = b - mean*scale; running stats update
+ *            var_mode 0: invstd = 1/sqrt(var_b + eps)        (torch, batchnorm.py:52-55)
+ *            var_mode 1: invstd = clamp(var_b, eps)^-1/2     (sync branch, batchnorm.py:127)
+ *   apply  : y = x*scale[c] + shift[c] (+res) -> act
+ */
+int64_t ssg_bn_workspace_bytes(int64_t P, int C);
+int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, void* ws, void* stream);
+int ssg_bn_finalize_f32(const double* sums, double count, int C, const float* weight, const float* bias,
+                        float eps, float momentum, int var_mode,
+                        float* running_mean, float* running_var,
+                        float* mean, float* invstd, float* scale, float* shift, void* stream);
+int ssg_bn_apply_f32(const float* x, int64_t P, int C, int ld, const float* scale, const float* shift,
+                     const float* res, int ldr, int act, float slope, float* y, int ldy, void* stream);
+/* backward: g = dy masked by the activation (y>0 ? 1 : slope), dres = g (if wanted);
+ *   stage 1: sums[0:C] = sum g, sums[C:2C] = sum g*xhat   (fp64; all-reduced for sync-BN)
+ *   apply  : dx = scale*(g - sums0/count - xhat*sums1/count); dweight = sums1, dbias = sums0 */
+int ssg_bn_bwd_reduce_f32(const float* x, const float* y, const float* dy, int64_t P, int C,
+                          int ldx, int ldy, int lddy, const float* mean, const float* invstd,
+                          int act, float slope, double* sums, void* ws, void* stream);
+int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float* dy, int64_t P, int C,
+                         int ldx, int ldy, int lddy, const float* mean, const float* invstd,
+                         const float* weight, const double* sums, double count, int act, float slope,
+                         float* dx, int lddx, float* dres, int lddres,
+                         float* dweight, float* dbias, void* stream);
+/* eval-mode / generic per-channel affine: y = x*scale + shift -> act (also used for bias+act) */
+
+/* ------------------------------------------------------------------ pool / unpool / upsample
+ * MaxPool2d(2,2,return_indices) archs.py:571,628-643; MaxUnpool2d(2,2) archs.py:572,648-659;
+ * Upsample(x2, bilinear, align_corners=True) archs.py:573,664,667.  The window argmax is kept
+ * as one byte (0..3 = dy*2+dx) per output element; ties resolve to the first in scan order
+ * and NaN wins, as ATen's CPU max_pool2d does. */
+int ssg_maxpool2x2_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, uint8_t* idx, void* stream);
+int ssg_maxpool2x2_bwd_f32(const float* dy, int lddy, const uint8_t* idx, int N, int H, int W, int C, float* dx, int lddx, void* stream);
+int ssg_maxunpool2x2_fwd_f32(const float* x, int ldx, const uint8_t* idx, int N, int OH, int OW, int C, float* y, int ldy, void* stream);
+int ssg_maxunpool2x2_bwd_f32(const float* dy, int lddy, const uint8_t* idx, int N, int OH, int OW, int C, float* dx, int lddx, void* stream);
+int ssg_upsample2x_bilinear_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, void* stream);
+int ssg_upsample2x_bilinear_bwd_f32(const float* dy, int lddy, int N, int H, int W, int C, float* dx, int lddx, void* stream);
+int ssg_upsample2x_nearest_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, void* stream);
+int ssg_upsample2x_nearest_bwd_f32(const float* dy, int lddy, int N, int H, int W, int C, float* dx, int lddx, void* stream);
+/* AdaptiveAvgPool2d((6,6)) + flatten in NCHW order (models_seg_gan.py:277,294-295):
+ * y[n, c*36 + oy*6 + ox]. */
+int ssg_adaptive_avgpool_flat_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, int OHW, float* y, void* stream);
+int ssg_adaptive_avgpool_flat_bwd_f32(const float* dy, int N, int H, int W, int C, int OHW, float* dx, int lddx, void* stream);
+
+/* ------------------------------------------------------------------ elementwise
+ * SPADE modulate out = x*(1+gamma)+beta (normalization.py:120) and its gradients
+ * dx = dy*(1+gamma), dgamma = dy*x, dbeta = dy.  gb holds gamma in channels [0,C) and beta
+ * in [C,2C) of one 2C-channel tensor (the fused gamma|beta conv output). */
+int ssg_spade_modulate_fwd_f32(const float* x, int ldx, const float* gb, int ldgb, int64_t P, int C, float* y, int ldy, void* stream);
+int ssg_spade_modulate_bwd_f32(const float* x, int ldx, const float* gb, int ldgb, const float* dy, int lddy, int64_t P, int C,
+                               float* dx, int lddx, float* dgb, int lddgb, void* stream);
+/* activation backward: dx = dy * (y > 0 ? 1 : slope) (+ add) */
+int ssg_act_bwd_f32(const float* y, int ldy, const float* dy, int lddy, int64_t P, int C, int act, float slope, float* dx, int lddx, void* stream);
+/* out = a + b (gradient accumulation across consumers) */
+int ssg_add_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* x[isnan(x)] = 0 in place, mask[i] = 1 where it was NaN (train_seg_gan.py:190) */
+int ssg_nan_to_zero_f32(float* x, int64_t n, uint8_t* mask, void* stream);
+/* out[i] = mask[i] ? 0 : g[i] (gradient of the masking above; out may alias g) */
+int ssg_mask_zero_f32(const float* g, const uint8_t* mask, int64_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------ fused segmentation loss
+ * One pass over logits x and target t (both NHWC-with-stride, C channels, S = H*W pixels per
+ * sample) produces everything train_seg_gan.py:191-198 needs:
+ *   res[0] = BCEDiceLoss (losses.py:274-302)        res[1] = MSELoss (train_seg_gan.py:195)
+ *   res[2] = StableBCE mean (losses.py:130-136)     res[3] = 1 - mean_n dice_n
+ *   res[4] = iou_score on channels [mc0,C) (metrics.py:6-22)   res[5] = dice_coef (metrics.py:25-35)
+ *   res[6] = bce-is-finite flag
+ *   stats[n*3 + {0,1,2}] = per-sample (sum p*t, sum p, sum t)  (kept for backward)
+ *   stats[3N + {0..4}]   = (|pred&tgt|, |pred|tgt|, sum p*t, sum p, sum t) on channels >= mc0
+ *                          (metric partial sums, all-reduced across ranks); stats holds 3N+5 doubles
+ * backward: dx = g_seg * dBCEDice/dx + g_mse * dMSE/dx, g_* read from device scalars. */
+int64_t ssg_seg_loss_workspace_bytes(int N, int64_t S, int C);
+int ssg_seg_loss_fwd_f32(const float* x, int ldx, const float* t, int ldt, int N, int64_t S, int C, int mc0,
+                         float* res, double* stats, void* ws, void* stream);
+int ssg_seg_loss_bwd_f32(const float* x, int ldx, const float* t, int ldt, int N, int64_t S, int C,
+                         const float* res, const double* stats, const float* g_seg, const float* g_mse,
+                         float* dx, int lddx, void* stream);
+/* BCEWithLogitsLoss(mean) of n logits x[i*ldx] against a constant label
+ * (train_seg_gan.py:204,221-222); backward writes dx[i*lddx] and zeros the pad columns. */
+int ssg_bce_logits_const_fwd_f32(const float* x, int n, int ldx, float label, float* loss, void* stream);
+int ssg_bce_logits_const_bwd_f32(const float* x, int n, int ldx, float label, const float* g, float* dx, int lddx, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * clip_gradient (srgan_utils.py:186-195: elementwise clamp to [-clip, clip]) fused with the
+ * torch.optim.Adam update (train_seg_gan.py:212-215,230-233) over a list of tensors.
+ * ptrs: device array of 4*ntensors pointers {param, grad, exp_avg, exp_avg_sq}; sizes and
+ * block_map as produced by the host helper in ssunet-gan_amd/optim.py.  clip <= 0 = off. */
+int ssg_clamp_adam_multi_f32(const void* const* ptrs, const int64_t* sizes, const int32_t* blk_tensor,
+                             const int32_t* blk_chunk, int nblocks, float clip, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, double bias_corr1,
+                             double bias_corr2_sqrt, void* stream);
+int ssg_clamp_f32(float* x, int64_t n, float lo, float hi, void* stream);
+
+/* per-channel sums over pixels: out[c] = sum_p x[p,c] (bias gradients) */
+int ssg_channel_sum_f32(const float* x, int64_t P, int C, int ld, float* out, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

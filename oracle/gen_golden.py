@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own modules (TEST INFRASTRUCTURE).
+
+Runs only in the build container, where /root/reference exists.  It imports the reference's
+`archs`, `models_seg_gan`, `losses`, `metrics`, `normalization` as-is (with an empty
+placeholder for the absent `torchvision`, which those files import but never touch on this
+path -- SURVEY.md 8c) and drives them through the exact train_seg_gan.py:182-233 sequence.
+The reference's driver files (train_seg_gan.py, srgan_utils.py) need cv2/albumentations/
+tensorboardX and cannot be imported, so the *sequence* is the restated one, the *modules*
+are the reference's.
+
+Fixtures carry seeds + inputs + outputs (+ per-parameter digests), never weights or code.
+
+    python oracle/gen_golden.py [--only step64|step256|blocks]
+"""
+import argparse
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference/scripts'
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit('reference not present; fixtures can only be generated in the build container')
+    warnings.filterwarnings('ignore')
+    tv = types.ModuleType('torchvision')
+    tvm = types.ModuleType('torchvision.models')
+    tv.models = tvm
+    sys.modules.setdefault('torchvision', tv)
+    sys.modules.setdefault('torchvision.models', tvm)
+    sys.path.insert(0, REF)
+    import archs, models_seg_gan, losses, metrics, normalization  # noqa
+    return archs, models_seg_gan, losses, metrics, normalization
+
+
+def digest(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().sqrt().item()])
+
+
+def param_digests(module, grads=False):
+    rows = []
+    for _, p in module.named_parameters():
+        src = p.grad if grads else p
+        rows.append(digest(src) if src is not None else np.zeros(3))
+    return np.stack(rows)
+
+
+def buffer_digests(module):
+    return np.stack([digest(b.float()) for _, b in module.named_buffers()])
+
+
+def synthetic_batch(n, h, w, seed=7, num_classes=3):
+    g = torch.Generator().manual_seed(seed)
+    inp = torch.randn(n, 3, h, w, generator=g)
+    tgt = (torch.rand(n, num_classes, h, w, generator=g) > 0.5).float()
+    return inp, tgt
+
+
+def ref_models(mods, seed=41):
+    archs, msg, losses, metrics, _ = mods
+    torch.manual_seed(seed)
+    G = msg.Generator(dict(arch='UNet_R_SS_v2', num_classes=3, input_channels=3, deep_supervision=False))
+    D = msg.Discriminator(3, kernel_size=3, n_channels=64, n_blocks=8, fc_size=1024)
+    og = torch.optim.Adam(params=filter(lambda p: p.requires_grad, G.parameters()), lr=2e-5)
+    od = torch.optim.Adam(params=filter(lambda p: p.requires_grad, D.parameters()), lr=2e-5)
+    return G, D, og, od
+
+
+def ref_step(mods, G, D, og, od, inp, tgt, rec):
+    """train_seg_gan.py:182-233 with the reference's modules; clip_gradient restated
+    (srgan_utils.py:186-195 is not importable: needs torchvision/PIL module constants)."""
+    _, _, losses, metrics, _ = mods
+    crit = losses.BCEDiceLoss()
+    adv_c = nn.BCEWithLogitsLoss()
+    con_c = nn.MSELoss()
+    G.train(); D.train()
+    out = G(inp)
+    out[torch.isnan(out)] = 0
+    out_m = out[:, 1:3].clone(); tar_m = tgt[:, 1:3].clone()
+    loss = crit(out, tgt)
+    closs = con_c(out, tgt)
+    iou = metrics.iou_score(out_m, tar_m)
+    dice = metrics.dice_coef(out_m, tar_m)
+    sd = D(out)
+    adv_g = adv_c(sd, torch.ones_like(sd))
+    tot = loss + 1e-4 * closs + 1e-3 * adv_g
+    og.zero_grad(); tot.backward()
+    rec['g_bwd_G'] = param_digests(G, True); rec['g_bwd_D'] = param_digests(D, True)
+    for grp in og.param_groups:
+        for p in grp['params']:
+            if p.grad is not None:
+                p.grad.data.clamp_(-0.8, 0.8)
+    og.step()
+    rec['g_step_G'] = param_digests(G)
+    hr = D(tgt); sr = D(out.detach())
+    adv_d = adv_c(sr, torch.zeros_like(sr)) + adv_c(hr, torch.ones_like(hr))
+    od.zero_grad(); adv_d.backward()
+    rec['d_bwd_D'] = param_digests(D, True)
+    for grp in od.param_groups:
+        for p in grp['params']:
+            if p.grad is not None:
+                p.grad.data.clamp_(-0.8, 0.8)
+    od.step()
+    rec['d_step_D'] = param_digests(D)
+    rec['bufs_G'] = buffer_digests(G); rec['bufs_D'] = buffer_digests(D)
+    rec['scalars'] = np.array([loss.item(), closs.item(), adv_g.item(), adv_d.item(), float(iou), float(dice)])
+    rec['logits'] = out.detach().numpy().copy()
+    rec['min_abs_logit'] = np.array(out.detach().abs().min().item())
+    rec['sd'] = sd.detach().numpy().copy(); rec['hr'] = hr.detach().numpy().copy(); rec['sr'] = sr.detach().numpy().copy()
+
+
+def gen_step(mods, name, n, h, w, steps, keep_logits=True):
+    G, D, og, od = ref_models(mods)
+    inp, tgt = synthetic_batch(n, h, w)
+    data = dict(seed_model=np.array(41), seed_batch=np.array(7), shape=np.array([n, 3, h, w]),
+                init_G=param_digests(G), init_D=param_digests(D),
+                param_names_G=np.array([k for k, _ in G.named_parameters()]),
+                param_names_D=np.array([k for k, _ in D.named_parameters()]),
+                state_keys_G=np.array(list(G.state_dict().keys())),
+                state_keys_D=np.array(list(D.state_dict().keys())))
+    if keep_logits:
+        data['input'] = inp.numpy(); data['target'] = tgt.numpy()
+    for s in range(steps):
+        rec = {}
+        ref_step(mods, G, D, og, od, inp, tgt, rec)
+        if not keep_logits:
+            lg = rec.pop('logits')
+            rec['logits_ds'] = lg[:, :, ::8, ::8].copy()        # down-sampled view + digest
+            rec['logits_digest'] = digest(torch.from_numpy(lg))
+        for k, v in rec.items():
+            data['s%d_%s' % (s, k)] = v
+        print(name, 'step', s, rec['scalars'])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **data)
+
+
+def _grad_pack(mod, x, extra_inputs=()):
+    x = x.clone().requires_grad_(True)
+    y = mod(x, *extra_inputs) if extra_inputs else mod(x)
+    g = torch.Generator().manual_seed(99)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    return y.detach().numpy(), dy.numpy(), x.grad.numpy(), param_digests(mod, True)
+
+
+def gen_blocks(mods):
+    """Block-level fixtures: seeds regenerate weights; store x, y, dy, dx, grad digests, buffers."""
+    archs, msg, losses, metrics, norm = mods
+    data = {}
+    g = torch.Generator().manual_seed(5)
+    # BasicBlock (archs.py:205-241), two shapes incl. a concat-sized input
+    for tag, (cin, cout, hw) in dict(bb_a=(8, 16, 12), bb_b=(48, 32, 8), bb_c=(3, 64, 16)).items():
+        torch.manual_seed(11)
+        m = archs.BasicBlock(cin, cout); m.train()
+        x = torch.randn(2, cin, hw, hw, generator=g)
+        y, dy, dx, gd = _grad_pack(m, x)
+        data.update({tag + '_x': x.numpy(), tag + '_y': y, tag + '_dy': dy, tag + '_dx': dx, tag + '_gd': gd,
+                     tag + '_bufs': buffer_digests(m), tag + '_cfg': np.array([cin, cout, hw])})
+    # SPADE as wired (normalization.py:67-122); nhidden = C/16 -> max(.,4)
+    for tag, (c, hw) in dict(sp_a=(64, 8), sp_b=(128, 6)).items():
+        torch.manual_seed(12)
+        m = norm.SPADE('spadebatch3x3', c, 3, c / 16); m.train()
+        x = torch.randn(2, c, hw, hw, generator=g)
+        x2 = x.clone().requires_grad_(True)
+        y = m(x2, x2)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(99))
+        y.backward(dy)
+        data.update({tag + '_x': x.numpy(), tag + '_y': y.detach().numpy(), tag + '_dy': dy.numpy(),
+                     tag + '_dx': x2.grad.numpy(), tag + '_gd': param_digests(m, True), tag + '_cfg': np.array([c, hw])})
+    # ConvolutionalBlock (models_seg_gan.py:13-64): stride 1 no-BN, stride 2 with BN
+    for tag, (cin, cout, s, bn, hw) in dict(cb_a=(3, 16, 1, False, 10), cb_b=(16, 16, 2, True, 10),
+                                            cb_c=(8, 24, 2, True, 7)).items():
+        torch.manual_seed(13)
+        m = msg.ConvolutionalBlock(cin, cout, 3, s, bn, 'LeakyReLu'); m.train()
+        x = torch.randn(2, cin, hw, hw, generator=g)
+        y, dy, dx, gd = _grad_pack(m, x)
+        data.update({tag + '_x': x.numpy(), tag + '_y': y, tag + '_dy': dy, tag + '_dx': dx, tag + '_gd': gd,
+                     tag + '_cfg': np.array([cin, cout, s, int(bn), hw])})
+    # Discriminator on a 96x96 input (adaptive pool 6x6 is then the identity) and 64x64 (2x2 -> 6x6)
+    for tag, hw in dict(d_96=96, d_64=64).items():
+        torch.manual_seed(14)
+        m = msg.Discriminator(3, 3, 8, 8, 1024); m.train()      # narrow D (n_channels=8) to keep it small
+        x = torch.randn(2, 3, hw, hw, generator=g)
+        y, dy, dx, gd = _grad_pack(m, x)
+        data.update({tag + '_x': x.numpy(), tag + '_y': y, tag + '_dy': dy, tag + '_dx': dx, tag + '_gd': gd})
+    # Losses / metrics (losses.py:274-302,130-136; metrics.py:6-35)
+    x = torch.randn(3, 3, 16, 16, generator=g) * 3
+    t = (torch.rand(3, 3, 16, 16, generator=g) > 0.5).float()
+    x2 = x.clone().requires_grad_(True)
+    l = losses.BCEDiceLoss()(x2, t); l.backward()
+    data.update(loss_x=x.numpy(), loss_t=t.numpy(), loss_val=np.array(l.item()), loss_dx=x2.grad.numpy(),
+                loss_bce=np.array(losses.StableBCELoss()(x, t).item()),
+                loss_iou=np.array(metrics.iou_score(x[:, 1:].clone(), t[:, 1:].clone())),
+                loss_dice=np.array(metrics.dice_coef(x[:, 1:].clone(), t[:, 1:].clone())))
+    np.savez_compressed(os.path.join(OUT, 'blocks.npz'), **data)
+    print('blocks.npz written,', len(data), 'arrays')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    mods = import_reference()
+    if a.only in (None, 'blocks'):
+        gen_blocks(mods)
+    if a.only in (None, 'step64'):
+        gen_step(mods, 'step_n2_64', 2, 64, 64, steps=2)
+    if a.only in (None, 'step256'):
+        gen_step(mods, 'step_n4_256', 4, 256, 256, steps=1, keep_logits=False)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,131 @@
+"""Block-level autograd Functions with hand-written backward passes.
+
+The reference expresses BasicBlock (archs.py:205-241) and SPADE (normalization.py:67-122) as
+chains of stock torch ops and lets autograd add the gradients of tensors that are consumed
+twice (block input -> conv1 and shortcut; SPADE input -> x2map and the modulation).  Here a
+whole block is ONE autograd node: the backward pass is an explicit kernel schedule in which
+those gradient sums ride the dgrad kernel's residual epilogue, the ReLU masks are folded into
+the batch-norm backward kernels, and `torch.cat` never materialises (two-pointer convs).
+"""
+import torch
+
+from . import ops
+from ._lib import ACT_NONE, ACT_RELU, call, ptr, stream_ptr
+from .ops import (_act_bwd, _bn_bwd_impl, _bn_fwd_impl, _channel_sum, _conv_dgrad_impl, _conv_fwd_impl, _conv_wgrad_impl,
+                  _ld, new_nhwc, to_nhwc)
+
+
+class _BasicBlockFn(torch.autograd.Function):
+    """relu(bn1(conv3x3(x))) -> bn2(conv3x3(.)) -> (+ conv1x1(x) | + x) -> relu, x = cat(x1, x2)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, wsc, eps1, mom1, eps2, mom2, stride, var_mode, group):
+        x1 = to_nhwc(x1)
+        x2 = to_nhwc(x2) if x2 is not None else None
+        c1 = _conv_fwd_impl(x1, x2, w1, None, stride, 1, ACT_NONE, 0.0)
+        y1, st1, world = _bn_fwd_impl(c1, g1, b1, rm1, rv1, None, eps1, mom1, ACT_RELU, 0.0, var_mode, group)
+        c2 = _conv_fwd_impl(y1, None, w2, None, 1, 1, ACT_NONE, 0.0)
+        if wsc is not None:
+            sc = _conv_fwd_impl(x1, x2, wsc, None, stride, 0, ACT_NONE, 0.0)
+        else:
+            if x2 is not None:
+                raise ValueError('identity shortcut with a two-tensor input')
+            sc = x1
+        out, st2, _ = _bn_fwd_impl(c2, g2, b2, rm2, rv2, sc, eps2, mom2, ACT_RELU, 0.0, var_mode, group)
+        ctx.save_for_backward(x1, x2, c1, y1, c2, out, w1, g1, w2, g2, wsc, st1, st2)
+        ctx.cfg = (stride, group, world)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x1, x2, c1, y1, c2, out, w1, g1, w2, g2, wsc, st1, st2 = ctx.saved_tensors
+        stride, group, world = ctx.cfg
+        dout = to_nhwc(dout)
+        n, ca, h, w = x1.shape
+        cb = x2.shape[1] if x2 is not None else 0
+        need_x1, need_x2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
+        # bn2 backward; dres = dout masked by the final ReLU = gradient of the shortcut branch
+        dc2, g, dg2, db2 = _bn_bwd_impl(c2, out, dout, g2, st2, ACT_RELU, 0.0, group, world, want_dres=True)
+        dw2 = _conv_wgrad_impl(y1, None, dc2, w2.shape, 1, 1)
+        dy1 = _conv_dgrad_impl(dc2, w2, 1, 1, y1.shape[2], y1.shape[3], 0, y1.shape[1])
+        dc1, _, dg1, db1 = _bn_bwd_impl(c1, y1, dy1, g1, st1, ACT_RELU, 0.0, group, world, want_dres=False)
+        dw1 = _conv_wgrad_impl(x1, x2, dc1, w1.shape, stride, 1)
+        dwsc = _conv_wgrad_impl(x1, x2, g, wsc.shape, stride, 0) if wsc is not None else None
+        dx1 = dx2 = None
+        if stride != 1 and (need_x1 or need_x2):
+            raise NotImplementedError('strided BasicBlock input gradient')
+        if need_x1:
+            part = _conv_dgrad_impl(g, wsc, 1, 0, h, w, 0, ca) if wsc is not None else g
+            dx1 = _conv_dgrad_impl(dc1, w1, 1, 1, h, w, 0, ca, res=part)
+        if need_x2:
+            part = _conv_dgrad_impl(g, wsc, 1, 0, h, w, ca, ca + cb)
+            dx2 = _conv_dgrad_impl(dc1, w1, 1, 1, h, w, ca, ca + cb, res=part)
+        return (dx1, dx2, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, dwsc,
+                None, None, None, None, None, None, None)
+
+
+def basic_block(x1, x2, conv1, bn1, conv2, bn2, shortcut_conv, group=None):
+    """Fused training-mode BasicBlock over nn.Conv2d / nn.BatchNorm2d parameter holders."""
+    for bn in (bn1, bn2):
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+    var_mode = 1 if group is not None else 0
+    return _BasicBlockFn.apply(x1, x2, conv1.weight, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                               conv2.weight, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+                               shortcut_conv.weight if shortcut_conv is not None else None,
+                               float(bn1.eps), float(bn1.momentum), float(bn2.eps), float(bn2.momentum),
+                               int(conv1.stride[0]), var_mode, group)
+
+
+class _SpadeFn(torch.autograd.Function):
+    """Self-conditioned SPADE: out = x*(1+gamma(a)) + beta(a), a = relu(shared(x2map(x))).
+    gamma and beta are produced by two convs writing the two channel halves of one buffer."""
+
+    @staticmethod
+    def forward(ctx, x, wx, bx, ws, bs, wg, bg, wb, bb, pad):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        seg = _conv_fwd_impl(x, None, wx, bx, 1, pad, ACT_NONE, 0.0)
+        a = _conv_fwd_impl(seg, None, ws, bs, 1, pad, ACT_RELU, 0.0)
+        gb = new_nhwc(n, 2 * c, h, w, x.device)
+        _conv_fwd_impl(a, None, wg, bg, 1, pad, ACT_NONE, 0.0, out=gb[:, :c])
+        _conv_fwd_impl(a, None, wb, bb, 1, pad, ACT_NONE, 0.0, out=gb[:, c:])
+        out = new_nhwc(n, c, h, w, x.device)
+        call('ssg_spade_modulate_fwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), n * h * w, c, ptr(out), _ld(out), stream_ptr())
+        ctx.save_for_backward(x, seg, a, gb, wx, ws, wg, wb)
+        ctx.pad = pad
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x, seg, a, gb, wx, ws, wg, wb = ctx.saved_tensors
+        pad = ctx.pad
+        dout = to_nhwc(dout)
+        n, c, h, w = x.shape
+        dxm = new_nhwc(n, c, h, w, x.device)
+        dgb = new_nhwc(n, 2 * c, h, w, x.device)
+        call('ssg_spade_modulate_bwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), ptr(dout), _ld(dout), n * h * w, c,
+             ptr(dxm), _ld(dxm), ptr(dgb), _ld(dgb), stream_ptr())
+        dga, dbe = dgb[:, :c], dgb[:, c:]
+        dwg = _conv_wgrad_impl(a, None, dga, wg.shape, 1, pad)
+        dwb = _conv_wgrad_impl(a, None, dbe, wb.shape, 1, pad)
+        dbias_gb = _channel_sum(dgb, 2 * c)
+        nh = a.shape[1]
+        da = _conv_dgrad_impl(dga, wg, 1, pad, h, w, 0, nh)
+        da = _conv_dgrad_impl(dbe, wb, 1, pad, h, w, 0, nh, res=da)
+        da = _act_bwd(a, da, ACT_RELU, 0.0)
+        dws = _conv_wgrad_impl(seg, None, da, ws.shape, 1, pad)
+        dbs = _channel_sum(da, nh)
+        dseg = _conv_dgrad_impl(da, ws, 1, pad, h, w, 0, seg.shape[1])
+        dwx = _conv_wgrad_impl(x, None, dseg, wx.shape, 1, pad)
+        dbx = _channel_sum(dseg, seg.shape[1])
+        dx = _conv_dgrad_impl(dseg, wx, 1, pad, h, w, 0, c, res=dxm) if ctx.needs_input_grad[0] else None
+        return dx, dwx, dbx, dws, dbs, dwg, dbias_gb[:c], dwb, dbias_gb[c:], None
+
+
+def spade_self(x, x2map, shared, gamma, beta):
+    """Fused SPADE(x, x) over the four nn.Conv2d parameter holders."""
+    return _SpadeFn.apply(x, x2map.weight, x2map.bias, shared.weight, shared.bias, gamma.weight, gamma.bias,
+                          beta.weight, beta.bias, int(x2map.padding[0]))

@@ -1,0 +1,14 @@
+// Error reporting + version for the C-ABI (include/ssunet_hip.h).
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void ssg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* ssg_last_error(void) { return g_err; }
+extern "C" int ssg_abi_version(void) { return 1; }

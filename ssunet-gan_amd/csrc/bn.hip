@@ -1,0 +1,258 @@
+// Training-mode batch norm over NHWC rows [P pixels][C channels] for gfx950 -- HBM-bound kernels.
+// ABI + reference citations: include/ssunet_hip.h (ssg_bn_*, ssg_channel_sum_f32).
+//
+// Layout choice: channels are the contiguous axis, so a wave's 64 lanes read TQ channel
+// quads x (64/TQ) consecutive pixels = whole 256-B..1-KiB contiguous segments with 16-B loads.
+// Per-channel reductions are "column" reductions: each thread keeps a float4 partial for its
+// channel quad over a strided pixel set, the pixel rows of a block are combined through LDS
+// in fp64, and every block writes one fp64 partial row; a second kernel adds the rows in
+// block order.  No atomics: results are bitwise reproducible and ready to be all-reduced
+// across ranks (sync-BN) between the two stages.
+#include "common.h"
+
+namespace {
+
+constexpr int RED_BLOCK = 256;
+constexpr int MAX_PARTS = 1024;
+
+struct RedGeom { int TQ, PR, groups, parts; long long rows_per_part; };
+
+__host__ RedGeom red_geom(long long P, int C) {
+  RedGeom g;
+  const int CQ = (C + 3) / 4;
+  g.TQ = CQ >= 64 ? 64 : 1;
+  if (CQ < 64) { while (g.TQ < CQ) g.TQ <<= 1; }
+  g.PR = RED_BLOCK / g.TQ;
+  g.groups = (CQ + g.TQ - 1) / g.TQ;
+  long long parts = (P + (long long)g.PR * 8 - 1) / ((long long)g.PR * 8);   // >= 8 rows per thread
+  if (parts > MAX_PARTS) parts = MAX_PARTS;
+  if (parts < 1) parts = 1;
+  g.rows_per_part = (P + parts - 1) / parts;
+  g.parts = (int)((P + g.rows_per_part - 1) / g.rows_per_part);
+  return g;
+}
+
+// MODE 0: (sum x, sum x^2)      MODE 1: (sum g, sum g*xhat), g = dy * act'(y)      MODE 2: (sum x, -)
+template <int MODE>
+__global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, long long P, int C,
+    int ldx, int ldy, int lddy, const float* __restrict__ mean, const float* __restrict__ invstd, int act, float slope,
+    int TQ, int PR, long long rows_per_part, double* __restrict__ part /* [parts][2][Cq4] */) {
+  __shared__ double red[2][RED_BLOCK][4];
+  const int tid = threadIdx.x;
+  const int tq = tid % TQ, pr = tid / TQ;
+  const int cq = blockIdx.y * TQ + tq;
+  const int CQ = (C + 3) / 4;
+  const bool cok = cq < CQ;
+  const long long p0 = (long long)blockIdx.x * rows_per_part;
+  long long p1 = p0 + rows_per_part; if (p1 > P) p1 = P;
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+  if (MODE == 1 && cok) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int c = 4 * cq + e; if (c < C) { mu[e] = mean[c]; is[e] = invstd[c]; } }
+  }
+  if (cok) {
+    for (long long p = p0 + pr; p < p1; p += PR) {
+      const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
+      if (MODE == 0) { s1 += xv; s2 += xv * xv; }
+      else if (MODE == 2) { s1 += xv; }
+      else {
+        f32x4 g = *(const f32x4*)(dy + p * lddy + 4 * cq);
+        if (act != SSG_ACT_NONE) {
+          const f32x4 yv = *(const f32x4*)(y + p * ldy + 4 * cq);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) g[e] *= (act == SSG_ACT_RELU ? 0.f : slope);
+        }
+        s1 += g; s2 += g * ((xv - mu) * is);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+  __syncthreads();
+  if (pr == 0 && cok) {
+    double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    for (int r = 0; r < PR; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a1[e] += red[0][r * TQ + tq][e]; a2[e] += red[1][r * TQ + tq][e]; }
+    double* dst = part + (size_t)blockIdx.x * 2 * (4 * CQ);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[4 * cq + e] = a1[e]; dst[4 * CQ + 4 * cq + e] = a2[e]; }
+  }
+}
+
+__global__ void col_reduce_final_kernel(const double* __restrict__ part, int parts, int C, int C4,
+                                        double* __restrict__ sums, float* __restrict__ fsum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a1 = 0, a2 = 0;
+  for (int b = 0; b < parts; ++b) { a1 += part[(size_t)b * 2 * C4 + c]; a2 += part[(size_t)b * 2 * C4 + C4 + c]; }
+  if (sums) { sums[c] = a1; sums[C + c] = a2; }
+  if (fsum) fsum[c] = (float)a1;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C, const float* __restrict__ weight,
+                                   const float* __restrict__ bias, float eps, float momentum, int var_mode,
+                                   float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                   float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[c] / count;
+  double var = sums[C + c] / count - m * m;
+  if (var < 0) var = 0;
+  double is;
+  if (var_mode == 0) is = 1.0 / sqrt(var + (double)eps);
+  else is = 1.0 / sqrt(var < (double)eps ? (double)eps : var);
+  const float mf = (float)m, isf = (float)is;
+  mean[c] = mf; invstd[c] = isf;
+  const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+  const float sc = w * isf;
+  scale[c] = sc; shift[c] = b - mf * sc;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+  if (running_var) {
+    const double unb = count > 1 ? var * count / (count - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long long P, int C, int ld,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ res, int ldr, int act, float slope,
+                                                       float* __restrict__ y, int ldy) {
+  const int CQ = C / 4;
+  const long long total = P * CQ;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    const f32x4 xv = *(const f32x4*)(x + p * ld + 4 * cq);
+    const f32x4 sc = *(const f32x4*)(scale + 4 * cq), sh = *(const f32x4*)(shift + 4 * cq);
+    f32x4 v = xv * sc + sh;
+    if (res) v += *(const f32x4*)(res + p * ldr + 4 * cq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ssg_act(v[e], act, slope);
+    *(f32x4*)(y + p * ldy + 4 * cq) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, long long P, int C, int ldx,
+    int ldy, int lddy, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ weight,
+    const double* __restrict__ sums, double count, int act, float slope, float* __restrict__ dx, int lddx,
+    float* __restrict__ dres, int lddres, float* __restrict__ dweight, float* __restrict__ dbias) {
+  const int CQ = C / 4;
+  const long long total = P * CQ;
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      if (dweight) dweight[c] = (float)sums[C + c];
+      if (dbias) dbias[c] = (float)sums[c];
+    }
+  }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    f32x4 g = *(const f32x4*)(dy + p * lddy + 4 * cq);
+    if (act != SSG_ACT_NONE) {
+      const f32x4 yv = *(const f32x4*)(y + p * ldy + 4 * cq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) g[e] *= (act == SSG_ACT_RELU ? 0.f : slope);
+    }
+    if (dres) *(f32x4*)(dres + p * lddres + 4 * cq) = g;
+    if (dx) {
+      const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * cq + e;
+        const float is = invstd[c];
+        const float xh = (xv[e] - mean[c]) * is;
+        const float m1 = (float)(sums[c] / count), m2 = (float)(sums[C + c] / count);
+        const float w = weight ? weight[c] : 1.f;
+        o[e] = (w * is) * (g[e] - m1 - xh * m2);
+      }
+      *(f32x4*)(dx + p * lddx + 4 * cq) = o;
+    }
+  }
+}
+
+int elem_grid(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <int MODE>
+int run_reduce(const float* x, const float* y, const float* dy, long long P, int C, int ldx, int ldy, int lddy,
+               const float* mean, const float* invstd, int act, float slope, double* sums, float* fsum, void* ws,
+               hipStream_t st) {
+  const RedGeom g = red_geom(P, C);
+  const int C4 = 4 * ((C + 3) / 4);
+  double* part = (double*)ws;
+  hipLaunchKernelGGL((col_reduce_kernel<MODE>), dim3((unsigned)g.parts, (unsigned)g.groups), dim3(RED_BLOCK), 0, st, x, y, dy,
+                     P, C, ldx, ldy, lddy, mean, invstd, act, slope, g.TQ, g.PR, g.rows_per_part, part);
+  SSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, st, part, g.parts, C, C4, sums, fsum);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t ssg_bn_workspace_bytes(int64_t P, int C) {
+  const RedGeom g = red_geom(P, C);
+  return (int64_t)g.parts * 2 * 4 * ((C + 3) / 4) * (int64_t)sizeof(double);
+}
+
+extern "C" int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, void* ws, void* stream) {
+  SSG_REQUIRE(x && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_stats: bad args");
+  SSG_REQUIRE(ld % 4 == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN, "bn_stats: alignment");
+  return run_reduce<0>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, 0, 0.f, sums, nullptr, ws, (hipStream_t)stream);
+}
+
+extern "C" int ssg_channel_sum_f32(const float* x, int64_t P, int C, int ld, float* out, void* ws, void* stream) {
+  SSG_REQUIRE(x && out && ws && P > 0 && C > 0, SSG_EINVAL, "channel_sum: bad args");
+  SSG_REQUIRE(ld % 4 == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN, "channel_sum: alignment");
+  return run_reduce<2>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, 0, 0.f, nullptr, out, ws, (hipStream_t)stream);
+}
+
+extern "C" int ssg_bn_finalize_f32(const double* sums, double count, int C, const float* weight, const float* bias,
+                                   float eps, float momentum, int var_mode, float* running_mean, float* running_var,
+                                   float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  SSG_REQUIRE(sums && mean && invstd && scale && shift && C > 0 && count > 0, SSG_EINVAL, "bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, (hipStream_t)stream, sums, count, C,
+                     weight, bias, eps, momentum, var_mode, running_mean, running_var, mean, invstd, scale, shift);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+extern "C" int ssg_bn_apply_f32(const float* x, int64_t P, int C, int ld, const float* scale, const float* shift,
+                                const float* res, int ldr, int act, float slope, float* y, int ldy, void* stream) {
+  SSG_REQUIRE(x && y && scale && shift && P > 0 && C > 0, SSG_EINVAL, "bn_apply: bad args");
+  SSG_REQUIRE(C % 4 == 0 && ld % 4 == 0 && ldy % 4 == 0 && (!res || ldr % 4 == 0), SSG_EALIGN, "bn_apply: C/ld multiples of 4");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, P, C, ld,
+                     scale, shift, res, ldr, act, slope, y, ldy);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+extern "C" int ssg_bn_bwd_reduce_f32(const float* x, const float* y, const float* dy, int64_t P, int C, int ldx, int ldy,
+                                     int lddy, const float* mean, const float* invstd, int act, float slope, double* sums,
+                                     void* ws, void* stream) {
+  SSG_REQUIRE(x && dy && mean && invstd && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_bwd_reduce: bad args");
+  SSG_REQUIRE(act == SSG_ACT_NONE || y, SSG_EINVAL, "bn_bwd_reduce: activation mask needs y");
+  SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_reduce: alignment");
+  return run_reduce<1>(x, y, dy, P, C, ldx, ldy, lddy, mean, invstd, act, slope, sums, nullptr, ws, (hipStream_t)stream);
+}
+
+extern "C" int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float* dy, int64_t P, int C, int ldx, int ldy,
+                                    int lddy, const float* mean, const float* invstd, const float* weight, const double* sums,
+                                    double count, int act, float slope, float* dx, int lddx, float* dres, int lddres,
+                                    float* dweight, float* dbias, void* stream) {
+  SSG_REQUIRE(x && dy && mean && invstd && sums && P > 0 && C > 0 && count > 0, SSG_EINVAL, "bn_bwd_apply: bad args");
+  SSG_REQUIRE(act == SSG_ACT_NONE || y, SSG_EINVAL, "bn_bwd_apply: activation mask needs y");
+  SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_apply: alignment");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, dy,
+                     P, C, ldx, ldy, lddy, mean, invstd, weight, sums, count, act, slope, dx, lddx, dres, lddres, dweight,
+                     dbias);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}

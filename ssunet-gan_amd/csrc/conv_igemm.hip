@@ -1,0 +1,316 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): fp32 in, fp32 accumulate on
+// v_mfma_f32_32x32x2_f32.  ABI + semantics: include/ssunet_hip.h (ssg_conv2d_igemm_f32).
+//
+// GEMM view: M = pixels of a (TH x 16) spatial patch of one image, N = output channels,
+// K = taps x input channels, walked 16 channels ("a K-step") at a time.
+//   - A tile [BM pixels][16 ch] is gathered from NHWC global memory: each lane fetches one
+//     16-byte channel quad of one pixel (64 B of contiguous channels per pixel per K-step,
+//     so a wave's loads cover whole 64-B segments); out-of-image taps are predicated to 0.
+//   - B tile [BN couts][16 k] comes from the pre-packed [Cout][Kp] weight matrix: rows are
+//     K-contiguous, so B loads are the same 16-byte-quad pattern.
+//   - both tiles sit in LDS as [row][16 + 4 pad] floats (80-B rows): ds_read_b128 of one
+//     row-per-lane is bank-conflict free (5*row mod 16 distinct within every 16-lane group).
+//   - MFMA operand trick: one ds_read_b128 gives a lane 4 consecutive channels; lanes 0-31
+//     read channels [8h, 8h+4), lanes 32-63 read [8h+4, 8h+8), so register j of the read is
+//     the (k=0 | k=1) operand pair (8h+j | 8h+4+j) of one 32x32x2 MFMA.  A and B use the same
+//     pairing, so 2+2 reads feed 4x(MI*NI) MFMAs.
+//   - register-staged double buffer: global loads for step s+1 are issued before the MFMAs
+//     of step s and written to the other LDS buffer after them; one barrier per K-step.
+//     Each K-step is MI*NI*8 MFMAs x 64 cycles per wave, long enough to cover L2/HBM latency.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  const float* in1; const float* in2;
+  const float* w; const float* bias; const float* res; float* out; float* bnpart;
+  int C1, C2, ld1, ld2;
+  int N, H, W;
+  int Kp, kmode;
+  int ldr, Cout, ldo;
+  int GH, GW, OH, OW;
+  int in_sy, in_sx, out_sy, out_sx, out_oy, out_ox;
+  int ntaps;
+  unsigned long long tap_bits;   // 6 bits per tap: (dy+2) | (dx+2)<<3
+  int act; float slope;
+  int tiles_x, tiles_y, nsteps;
+};
+
+constexpr int LDS_ROW = 20;   // floats per LDS row (16 data + 4 pad = 80 bytes)
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int TH = BM / 16;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int A_LD = BM * 4 / 256;                   // float4 loads per thread for A
+  constexpr int B_LD = (BN * 4 + 255) / 256;           // ... for B
+  static_assert(MI >= 1 && NI >= 1, "wave tile");
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_ROW];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * LDS_ROW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- tile decode
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int n = bid / a.tiles_y;
+  const int n0 = blockIdx.y * BN;
+  const int Cin = a.C1 + a.C2;
+
+  // ---- per-thread A gather coordinates (fixed over the K loop)
+  int a_iy0[A_LD], a_ix0[A_LD];
+  bool a_ok[A_LD];
+  const int q = tid & 3;
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) {
+    const int p = (tid >> 2) + 64 * j;
+    const int gy = ty * TH + (p >> 4), gx = tx * 16 + (p & 15);
+    a_ok[j] = (gy < a.GH) && (gx < a.GW);
+    a_iy0[j] = gy * a.in_sy;
+    a_ix0[j] = gx * a.in_sx;
+  }
+  // ---- per-thread B rows
+  const float* b_ptr[B_LD];
+  bool b_ok[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int r = (tid >> 2) + 64 * j;
+    b_ok[j] = (r < BN) && (n0 + r < a.Cout);
+    b_ptr[j] = a.w + (size_t)(n0 + (b_ok[j] ? r : 0)) * a.Kp + 4 * q;
+  }
+
+  f32x4 ra[A_LD], rb[B_LD];
+
+  auto load_step = [&](int s) {
+    int t, c;
+    if (a.kmode == 0) {
+      const int chunk = s / a.ntaps;
+      t = s - chunk * a.ntaps;
+      c = chunk * 16 + 4 * q;
+    } else {
+      const int k = s * 16 + 4 * q;
+      t = k / Cin;
+      c = k - t * Cin;
+    }
+    const bool tv = t < a.ntaps;
+    const int tb = (int)((a.tap_bits >> (6 * (tv ? t : 0))) & 63ull);
+    const int dy = (tb & 7) - 2, dx = (tb >> 3) - 2;
+    const float* src; int ld, cc;
+    if (c < a.C1) { src = a.in1; ld = a.ld1; cc = c; }
+    else          { src = a.in2; ld = a.ld2; cc = c - a.C1; }
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+      const bool ok = tv && a_ok[j] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *(const f32x4*)(src + ((size_t)(n * a.H + iy) * a.W + ix) * ld + cc);
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ok[j]) v = *(const f32x4*)(b_ptr[j] + (size_t)s * 16);
+      rb[j] = v;
+    }
+  };
+  auto store_step = [&](int buf) {
+    float* Ab = As + buf * BM * LDS_ROW;
+    float* Bb = Bs + buf * BN * LDS_ROW;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j)
+      *(f32x4*)(Ab + ((tid >> 2) + 64 * j) * LDS_ROW + 4 * q) = ra[j];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const int r = (tid >> 2) + 64 * j;
+      if (r < BN) *(f32x4*)(Bb + r * LDS_ROW + 4 * q) = rb[j];
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int s = 0; s < a.nsteps; ++s) {
+    const int buf = s & 1;
+    const bool more = (s + 1) < a.nsteps;
+    if (more) load_step(s + 1);
+    const float* Ab = As + buf * BM * LDS_ROW + (wm * WTM + l31) * LDS_ROW + 4 * half;
+    const float* Bb = Bs + buf * BN * LDS_ROW + (wn * WTN + l31) * LDS_ROW + 4 * half;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *(const f32x4*)(Ab + i * 32 * LDS_ROW + 8 * h);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = *(const f32x4*)(Bb + j * 32 * LDS_ROW + 8 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool want_bn = a.bnpart != nullptr;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn * WTN + j * 32 + l31;
+    const bool cok = co < a.Cout;
+    const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int gy = ty * TH + (p >> 4), gx = tx * 16 + (p & 15);
+        if (gy < a.GH && gx < a.GW) {
+          const size_t pix = ((size_t)(n * a.OH + gy * a.out_sy + a.out_oy) * a.OW + gx * a.out_sx + a.out_ox);
+          float v = acc[i][j][r] + bv;
+          if (want_bn) { s1 += v; s2 += v * v; }
+          if (cok) {
+            if (a.res) v += a.res[pix * a.ldr + co];
+            if (a.act == SSG_ACT_RELU) v = v < 0.f ? 0.f : v;
+            else if (a.act == SSG_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+            a.out[pix * a.ldo + co] = v;
+          } else if (co < ((a.Cout + 3) & ~3)) {
+            a.out[pix * a.ldo + co] = 0.f;      // keep pad channels finite (zero)
+          }
+        }
+      }
+    }
+    if (want_bn) {
+      // combine the two lane halves (same column), then the WAVES_M waves through LDS
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      __syncthreads();                      // LDS tiles are dead now
+      float* red = lds;                     // [WAVES_M][2][BN]
+      if (half == 0) {
+        red[(wm * 2 + 0) * BN + wn * WTN + j * 32 + l31] = s1;
+        red[(wm * 2 + 1) * BN + wn * WTN + j * 32 + l31] = s2;
+      }
+      __syncthreads();
+      if (wm == 0 && half == 0 && cok) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WAVES_M; ++k) {
+          t1 += red[(k * 2 + 0) * BN + wn * WTN + j * 32 + l31];
+          t2 += red[(k * 2 + 1) * BN + wn * WTN + j * 32 + l31];
+        }
+        float* dst = a.bnpart + (size_t)blockIdx.x * 2 * a.Cout;
+        dst[co] = t1;
+        dst[a.Cout + co] = t2;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  constexpr int TH = BM / 16;
+  a.tiles_x = (a.GW + 15) / 16;
+  a.tiles_y = (a.GH + TH - 1) / TH;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)((a.Cout + BN - 1) / BN));
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), 0, st, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+// tile choice: wide-N tiles for Cout >= 96, narrow for the 64/32/small-Cout layers.
+int pick_variant(const ssg_conv_desc* d) {
+  if (d->Cout > 64) return 0;       // 128 x 128
+  if (d->Cout > 32) return 1;       // 256 x 64
+  return 2;                         // 256 x 32
+}
+
+int validate(const ssg_conv_desc* d) {
+  SSG_REQUIRE(d != nullptr, SSG_EINVAL, "conv: null desc");
+  SSG_REQUIRE(d->in1 && d->w && d->out, SSG_EINVAL, "conv: null pointer");
+  SSG_REQUIRE(d->C1 > 0 && d->C1 % 4 == 0 && d->C2 >= 0 && d->C2 % 4 == 0, SSG_EINVAL,
+              "conv: C1=%d C2=%d must be multiples of 4", d->C1, d->C2);
+  SSG_REQUIRE(d->C2 == 0 || d->in2, SSG_EINVAL, "conv: C2 > 0 needs in2");
+  SSG_REQUIRE(d->ld1 >= d->C1 && d->ld1 % 4 == 0 && (d->C2 == 0 || (d->ld2 >= d->C2 && d->ld2 % 4 == 0)), SSG_EALIGN,
+              "conv: input pixel strides");
+  SSG_REQUIRE(ssg_aligned16(d->in1) && ssg_aligned16(d->in2) && ssg_aligned16(d->w), SSG_EALIGN, "conv: 16-B alignment");
+  SSG_REQUIRE(d->Kp > 0 && d->Kp % 16 == 0, SSG_EINVAL, "conv: Kp=%d", d->Kp);
+  SSG_REQUIRE(d->ntaps >= 1 && d->ntaps <= SSG_MAX_TAPS, SSG_EINVAL, "conv: ntaps=%d", d->ntaps);
+  const int Cin = d->C1 + d->C2;
+  if (d->kmode == 0) {
+    SSG_REQUIRE(Cin % 16 == 0 && d->C1 % 16 == 0, SSG_EINVAL, "conv: kmode 0 needs 16-channel multiples (C1=%d C2=%d)", d->C1, d->C2);
+    SSG_REQUIRE(d->Kp == Cin * d->ntaps, SSG_EINVAL, "conv: Kp=%d != Cin*ntaps=%d", d->Kp, Cin * d->ntaps);
+  } else {
+    SSG_REQUIRE(d->kmode == 1, SSG_EINVAL, "conv: kmode=%d", d->kmode);
+    SSG_REQUIRE(d->Kp >= Cin * d->ntaps && d->Kp < Cin * d->ntaps + 16, SSG_EINVAL, "conv: Kp=%d vs K=%d", d->Kp, Cin * d->ntaps);
+  }
+  SSG_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->GH > 0 && d->GW > 0 && d->Cout > 0, SSG_EINVAL, "conv: empty dims");
+  SSG_REQUIRE(d->ldo >= d->Cout, SSG_EINVAL, "conv: ldo=%d < Cout=%d", d->ldo, d->Cout);
+  SSG_REQUIRE((d->GH - 1) * d->out_sy + d->out_oy < d->OH && (d->GW - 1) * d->out_sx + d->out_ox < d->OW, SSG_EINVAL,
+              "conv: pixel grid exceeds the output image");
+  SSG_REQUIRE(d->res == nullptr || d->ldr >= d->Cout, SSG_EINVAL, "conv: residual stride");
+  for (int t = 0; t < d->ntaps; ++t)
+    SSG_REQUIRE(d->dy[t] >= -2 && d->dy[t] <= 5 && d->dx[t] >= -2 && d->dx[t] <= 5, SSG_EINVAL, "conv: tap offset out of range");
+  SSG_REQUIRE((int64_t)d->N * d->H * d->W * (int64_t)(d->ld1 > d->ld2 ? d->ld1 : d->ld2) < (1ll << 40), SSG_EINVAL, "conv: tensor too large");
+  return SSG_OK;
+}
+
+ConvArgs to_args(const ssg_conv_desc* d) {
+  ConvArgs a;
+  a.in1 = d->in1; a.in2 = d->C2 ? d->in2 : d->in1; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out;
+  a.bnpart = d->bnpart;
+  a.C1 = d->C1; a.C2 = d->C2; a.ld1 = d->ld1; a.ld2 = d->C2 ? d->ld2 : d->ld1;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Kp = d->Kp; a.kmode = d->kmode;
+  a.ldr = d->ldr; a.Cout = d->Cout; a.ldo = d->ldo;
+  a.GH = d->GH; a.GW = d->GW; a.OH = d->OH; a.OW = d->OW;
+  a.in_sy = d->in_sy; a.in_sx = d->in_sx; a.out_sy = d->out_sy; a.out_sx = d->out_sx;
+  a.out_oy = d->out_oy; a.out_ox = d->out_ox;
+  a.ntaps = d->ntaps;
+  a.tap_bits = 0;
+  for (int t = 0; t < d->ntaps; ++t)
+    a.tap_bits |= (unsigned long long)(((d->dy[t] + 2) & 7) | (((d->dx[t] + 2) & 7) << 3)) << (6 * t);
+  a.act = d->act; a.slope = d->slope;
+  a.nsteps = d->Kp / 16;
+  a.tiles_x = a.tiles_y = 0;
+  return a;
+}
+
+}  // namespace
+
+extern "C" int ssg_conv2d_igemm_mtiles(const ssg_conv_desc* d) {
+  if (!d) return SSG_EINVAL;
+  const int th = (pick_variant(d) == 0) ? 8 : 16;
+  return ((d->GW + 15) / 16) * ((d->GH + th - 1) / th) * d->N;
+}
+
+extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
+  int rc = validate(d);
+  if (rc != SSG_OK) return rc;
+  const ConvArgs a = to_args(d);
+  hipStream_t st = (hipStream_t)stream;
+  switch (pick_variant(d)) {
+    case 0: return launch<128, 128, 2, 2>(a, st);
+    case 1: return launch<256, 64, 4, 1>(a, st);
+    default: return launch<256, 32, 4, 1>(a, st);
+  }
+}

@@ -1,0 +1,183 @@
+// Element-wise kernels for gfx950 (HBM-bound, 16 B per lane): SPADE modulate fwd/bwd,
+// activation backward, add, NaN masking, clamp, fused clamp+Adam.
+// ABI + reference citations: include/ssunet_hip.h.
+#include "common.h"
+
+namespace {
+
+int elem_grid(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+#define GRID_STRIDE(i, total) \
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (total); i += (long long)gridDim.x * 256)
+
+__global__ __launch_bounds__(256) void modulate_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gb, int ldgb,
+                                                           long long P, int C, float* __restrict__ y, int ldy) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, P * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
+    const f32x4 g = *(const f32x4*)(gb + p * ldgb + 4 * cq), b = *(const f32x4*)(gb + p * ldgb + C + 4 * cq);
+    *(f32x4*)(y + p * ldy + 4 * cq) = xv * (1.f + g) + b;
+  }
+}
+__global__ __launch_bounds__(256) void modulate_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gb, int ldgb,
+                                                           const float* __restrict__ dy, int lddy, long long P, int C,
+                                                           float* __restrict__ dx, int lddx, float* __restrict__ dgb, int lddgb) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, P * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
+    const f32x4 g = *(const f32x4*)(gb + p * ldgb + 4 * cq);
+    const f32x4 d = *(const f32x4*)(dy + p * lddy + 4 * cq);
+    *(f32x4*)(dx + p * lddx + 4 * cq) = d * (1.f + g);
+    *(f32x4*)(dgb + p * lddgb + 4 * cq) = d * xv;
+    *(f32x4*)(dgb + p * lddgb + C + 4 * cq) = d;
+  }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dy, int lddy,
+                                                      long long P, int C, int act, float slope, float* __restrict__ dx, int lddx) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, P * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    const f32x4 yv = *(const f32x4*)(y + p * ldy + 4 * cq);
+    f32x4 d = *(const f32x4*)(dy + p * lddy + 4 * cq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) d[e] *= (act == SSG_ACT_RELU ? 0.f : (act == SSG_ACT_LRELU ? slope : 1.f));
+    *(f32x4*)(dx + p * lddx + 4 * cq) = d;
+  }
+}
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ o) {
+  const long long nq = n / 4;
+  GRID_STRIDE(i, nq) { *(f32x4*)(o + 4 * i) = *(const f32x4*)(a + 4 * i) + *(const f32x4*)(b + 4 * i); }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const long long j = nq * 4 + threadIdx.x; o[j] = a[j] + b[j]; }
+}
+__global__ __launch_bounds__(256) void nan_to_zero_kernel(float* __restrict__ x, long long n, uint8_t* __restrict__ mask) {
+  GRID_STRIDE(i, n) { const float v = x[i]; const bool isn = v != v; if (isn) x[i] = 0.f; if (mask) mask[i] = isn ? 1 : 0; }
+}
+__global__ __launch_bounds__(256) void mask_zero_kernel(const float* g, const uint8_t* __restrict__ mask, long long n, float* out) {
+  GRID_STRIDE(i, n) { out[i] = mask[i] ? 0.f : g[i]; }
+}
+__global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ x, long long n, float lo, float hi) {
+  GRID_STRIDE(i, n) { float v = x[i]; v = v < lo ? lo : v; v = v > hi ? hi : v; x[i] = v; }   // NaN stays NaN (torch.clamp)
+}
+
+// ---------------------------------------------------------------- fused clamp + Adam, multi-tensor
+// One workgroup per (tensor, 4096-element chunk); arithmetic order follows torch.optim.Adam's
+// single-tensor path: lerp exp_avg, mul/addcmul exp_avg_sq, denom = sqrt(v)/bc2_sqrt + eps,
+// param += -(lr/bc1) * m/denom.
+constexpr int ADAM_CHUNK = 4096;
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float clip, float lr_bc1, float omb1, float b2,
+                                          float omb2, float eps, float wd, float bc2s) {
+  if (clip > 0.f) { g = g < -clip ? -clip : g; g = g > clip ? clip : g; }
+  if (wd != 0.f) g = g + wd * p;
+  m = m + (g - m) * omb1;
+  v = v * b2;
+  v = v + (omb2 * g) * g;
+  const float denom = sqrtf(v) / bc2s + eps;
+  p = p - lr_bc1 * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void clamp_adam_kernel(const void* const* __restrict__ ptrs, const long long* __restrict__ sizes,
+                                                         const int* __restrict__ blk_tensor, const int* __restrict__ blk_chunk,
+                                                         float clip, float lr_bc1, float b1, float b2, float omb2, float eps, float wd, float bc2s) {
+  const int t = blk_tensor[blockIdx.x];
+  const long long base = (long long)blk_chunk[blockIdx.x] * ADAM_CHUNK;
+  float* P = (float*)ptrs[4 * t + 0];
+  float* G = (float*)ptrs[4 * t + 1];
+  float* M = (float*)ptrs[4 * t + 2];
+  float* V = (float*)ptrs[4 * t + 3];
+  long long n = sizes[t] - base;
+  if (n > ADAM_CHUNK) n = ADAM_CHUNK;
+  const bool vec = ((((uintptr_t)P | (uintptr_t)G | (uintptr_t)M | (uintptr_t)V) & 15) == 0);
+  if (vec) {
+    const int nq = (int)(n / 4);
+    for (int i = threadIdx.x; i < nq; i += 256) {
+      const long long o = base + 4 * i;
+      f32x4 p = *(f32x4*)(P + o), g = *(f32x4*)(G + o), m = *(f32x4*)(M + o), v = *(f32x4*)(V + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float pe = p[e], me = m[e], ve = v[e]; adam_elem(pe, g[e], me, ve, clip, lr_bc1, b1, b2, omb2, eps, wd, bc2s); p[e] = pe; m[e] = me; v[e] = ve; }
+      *(f32x4*)(P + o) = p; *(f32x4*)(M + o) = m; *(f32x4*)(V + o) = v;
+      if (clip > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float ge = g[e]; ge = ge < -clip ? -clip : ge; ge = ge > clip ? clip : ge; g[e] = ge; }
+        *(f32x4*)(G + o) = g;                    // clip_gradient clamps .grad in place
+      }
+    }
+    for (int i = nq * 4 + threadIdx.x; i < n; i += 256) {
+      const long long o = base + i;
+      float g = G[o];
+      adam_elem(P[o], g, M[o], V[o], clip, lr_bc1, b1, b2, omb2, eps, wd, bc2s);
+      if (clip > 0.f) { g = g < -clip ? -clip : g; g = g > clip ? clip : g; G[o] = g; }
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const long long o = base + i;
+      float g = G[o];
+      adam_elem(P[o], g, M[o], V[o], clip, lr_bc1, b1, b2, omb2, eps, wd, bc2s);
+      if (clip > 0.f) { g = g < -clip ? -clip : g; g = g > clip ? clip : g; G[o] = g; }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ssg_spade_modulate_fwd_f32(const float* x, int ldx, const float* gb, int ldgb, int64_t P, int C, float* y, int ldy, void* stream) {
+  SSG_REQUIRE(x && gb && y && P > 0 && C > 0 && C % 4 == 0 && ldgb >= 2 * C, SSG_EINVAL, "modulate: bad args");
+  hipLaunchKernelGGL(modulate_fwd_kernel, dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, gb, ldgb, (long long)P, C, y, ldy);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_spade_modulate_bwd_f32(const float* x, int ldx, const float* gb, int ldgb, const float* dy, int lddy, int64_t P, int C,
+                                          float* dx, int lddx, float* dgb, int lddgb, void* stream) {
+  SSG_REQUIRE(x && gb && dy && dx && dgb && P > 0 && C > 0 && C % 4 == 0 && ldgb >= 2 * C && lddgb >= 2 * C, SSG_EINVAL, "modulate_bwd: bad args");
+  hipLaunchKernelGGL(modulate_bwd_kernel, dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, gb, ldgb, dy, lddy, (long long)P, C, dx, lddx, dgb, lddgb);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_act_bwd_f32(const float* y, int ldy, const float* dy, int lddy, int64_t P, int C, int act, float slope, float* dx, int lddx, void* stream) {
+  SSG_REQUIRE(y && dy && dx && P > 0 && C > 0 && C % 4 == 0, SSG_EINVAL, "act_bwd: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, dy, lddy, (long long)P, C, act, slope, dx, lddx);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_add_f32(const float* a, const float* b, int64_t n, float* out, void* stream) {
+  SSG_REQUIRE(a && b && out && n > 0, SSG_EINVAL, "add: bad args");
+  SSG_REQUIRE(ssg_aligned16(a) && ssg_aligned16(b) && ssg_aligned16(out), SSG_EALIGN, "add: alignment");
+  hipLaunchKernelGGL(add_kernel, dim3(elem_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, (long long)n, out);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_nan_to_zero_f32(float* x, int64_t n, uint8_t* mask, void* stream) {
+  SSG_REQUIRE(x && n > 0, SSG_EINVAL, "nan_to_zero: bad args");
+  hipLaunchKernelGGL(nan_to_zero_kernel, dim3(elem_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, mask);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_mask_zero_f32(const float* g, const uint8_t* mask, int64_t n, float* out, void* stream) {
+  SSG_REQUIRE(g && mask && out && n > 0, SSG_EINVAL, "mask_zero: bad args");
+  hipLaunchKernelGGL(mask_zero_kernel, dim3(elem_grid(n)), dim3(256), 0, (hipStream_t)stream, g, mask, (long long)n, out);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_clamp_f32(float* x, int64_t n, float lo, float hi, void* stream) {
+  SSG_REQUIRE(x && n > 0, SSG_EINVAL, "clamp: bad args");
+  hipLaunchKernelGGL(clamp_kernel, dim3(elem_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, lo, hi);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_clamp_adam_multi_f32(const void* const* ptrs, const int64_t* sizes, const int32_t* blk_tensor, const int32_t* blk_chunk,
+                                        int nblocks, float clip, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                        double bias_corr1, double bias_corr2_sqrt, void* stream) {
+  SSG_REQUIRE(ptrs && sizes && blk_tensor && blk_chunk && nblocks > 0, SSG_EINVAL, "adam: bad args");
+  SSG_REQUIRE(bias_corr1 > 0.0 && bias_corr2_sqrt > 0.0, SSG_EINVAL, "adam: bias corrections");
+  hipLaunchKernelGGL(clamp_adam_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, ptrs, (const long long*)sizes,
+                     blk_tensor, blk_chunk, clip, (float)(lr / bias_corr1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)weight_decay, (float)bias_corr2_sqrt);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}

@@ -1,0 +1,350 @@
+// Pool / unpool / upsample / adaptive-avgpool / layout kernels for gfx950 (HBM-bound).
+// ABI + reference citations: include/ssunet_hip.h.  One thread handles one 16-byte channel
+// quad of one pixel, so consecutive lanes read/write consecutive 16-B pieces of an NHWC row.
+#include "common.h"
+
+namespace {
+
+int elem_grid(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#define GRID_STRIDE(i, total) \
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (total); i += (long long)gridDim.x * 256)
+
+// ---------------------------------------------------------------- max pool 2x2 (+argmax byte)
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
+                                                          float* __restrict__ y, int ldy, uint8_t* __restrict__ idx) {
+  const int OH = H / 2, OW = W / 2, CQ = C / 4;
+  const long long total = (long long)N * OH * OW * CQ;
+  GRID_STRIDE(i, total) {
+    const int cq = (int)(i % CQ); long long r = i / CQ;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH); const int n = (int)(r / OH);
+    const float* b = x + ((size_t)(n * H + 2 * oy) * W + 2 * ox) * ldx + 4 * cq;
+    f32x4 best = *(const f32x4*)b;
+    int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const f32x4 v = *(const f32x4*)(b + ((size_t)(k >> 1) * W + (k & 1)) * ldx);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = k; }   // first max wins, NaN wins (ATen CPU)
+    }
+    const size_t o = ((size_t)(n * OH + oy) * OW + ox);
+    *(f32x4*)(y + o * ldy + 4 * cq) = best;
+    *(uint32_t*)(idx + o * C + 4 * cq) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+  }
+}
+
+// scatter src[n,oy,ox,c] to the argmax position of its 2x2 window in dst (zeros elsewhere):
+// = max-pool backward and = max-unpool forward.
+__global__ __launch_bounds__(256) void scatter2x2_kernel(const float* __restrict__ src, int lds_, const uint8_t* __restrict__ idx,
+                                                         int N, int OH, int OW, int C, float* __restrict__ dst, int ldd) {
+  const int CQ = C / 4, H = OH * 2, W = OW * 2;
+  const long long total = (long long)N * OH * OW * CQ;
+  GRID_STRIDE(i, total) {
+    const int cq = (int)(i % CQ); long long r = i / CQ;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH); const int n = (int)(r / OH);
+    const size_t o = ((size_t)(n * OH + oy) * OW + ox);
+    const f32x4 v = *(const f32x4*)(src + o * lds_ + 4 * cq);
+    const uint32_t pk = *(const uint32_t*)(idx + o * C + 4 * cq);
+    float* b = dst + ((size_t)(n * H + 2 * oy) * W + 2 * ox) * ldd + 4 * cq;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (((pk >> (8 * e)) & 255u) == (uint32_t)k) ? v[e] : 0.f;
+      *(f32x4*)(b + ((size_t)(k >> 1) * W + (k & 1)) * ldd) = w;
+    }
+  }
+}
+
+// gather dst[n,oy,ox,c] = src[window position idx]: = max-unpool backward.
+__global__ __launch_bounds__(256) void gather2x2_kernel(const float* __restrict__ src, int lds_, const uint8_t* __restrict__ idx,
+                                                        int N, int OH, int OW, int C, float* __restrict__ dst, int ldd) {
+  const int CQ = C / 4, H = OH * 2, W = OW * 2;
+  const long long total = (long long)N * OH * OW * CQ;
+  GRID_STRIDE(i, total) {
+    const int cq = (int)(i % CQ); long long r = i / CQ;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH); const int n = (int)(r / OH);
+    const size_t o = ((size_t)(n * OH + oy) * OW + ox);
+    const uint32_t pk = *(const uint32_t*)(idx + o * C + 4 * cq);
+    const float* b = src + ((size_t)(n * H + 2 * oy) * W + 2 * ox) * lds_ + 4 * cq;
+    f32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = (pk >> (8 * e)) & 3;
+      out[e] = b[((size_t)(k >> 1) * W + (k & 1)) * lds_ + e];
+    }
+    *(f32x4*)(dst + o * ldd + 4 * cq) = out;
+  }
+}
+
+// ---------------------------------------------------------------- bilinear x2, align_corners=True
+// ATen: scale = (in-1)/(out-1) (0 if out==1); src = scale*dst; i0 = (int)src; i1 = i0 + (i0 < in-1);
+//       l1 = src - i0; l0 = 1 - l1.
+__device__ __forceinline__ void lerp_coord(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+  const float s = scale * (float)o;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
+                                                           float* __restrict__ y, int ldy, float sy, float sx) {
+  const int OH = 2 * H, OW = 2 * W, CQ = C / 4;
+  const long long total = (long long)N * OH * OW * CQ;
+  GRID_STRIDE(i, total) {
+    const int cq = (int)(i % CQ); long long r = i / CQ;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH); const int n = (int)(r / OH);
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    lerp_coord(oy, sy, H, y0, y1, ly0, ly1);
+    lerp_coord(ox, sx, W, x0, x1, lx0, lx1);
+    const float* b = x + (size_t)n * H * W * ldx + 4 * cq;
+    const f32x4 v00 = *(const f32x4*)(b + ((size_t)y0 * W + x0) * ldx), v01 = *(const f32x4*)(b + ((size_t)y0 * W + x1) * ldx);
+    const f32x4 v10 = *(const f32x4*)(b + ((size_t)y1 * W + x0) * ldx), v11 = *(const f32x4*)(b + ((size_t)y1 * W + x1) * ldx);
+    const f32x4 o = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+    *(f32x4*)(y + ((size_t)(n * OH + oy) * OW + ox) * ldy + 4 * cq) = o;
+  }
+}
+
+// backward as a gather over input pixels (deterministic): each input row iy collects from the
+// few output rows whose (y0|y1) equals iy, recomputed with the forward's exact arithmetic.
+__device__ __forceinline__ void cand_range(int i, float scale, int out, int& lo, int& hi) {
+  if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+  lo = (int)floorf((float)(i - 1) / scale) - 1;
+  hi = (int)ceilf((float)(i + 1) / scale) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int lddy, int N, int H, int W, int C,
+                                                           float* __restrict__ dx, int lddx, float sy, float sx) {
+  const int OH = 2 * H, OW = 2 * W, CQ = C / 4;
+  const long long total = (long long)N * H * W * CQ;
+  GRID_STRIDE(i, total) {
+    const int cq = (int)(i % CQ); long long r = i / CQ;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H); const int n = (int)(r / H);
+    int ylo, yhi, xlo, xhi;
+    cand_range(iy, sy, OH, ylo, yhi);
+    cand_range(ix, sx, OW, xlo, xhi);
+    f32x4 acc = {0, 0, 0, 0};
+    const float* b = dy + (size_t)n * OH * OW * lddy + 4 * cq;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      int y0, y1; float ly0, ly1;
+      lerp_coord(oy, sy, H, y0, y1, ly0, ly1);
+      float wy = 0.f;
+      if (y0 == iy) wy += ly0;
+      if (y1 == iy) wy += ly1;
+      if (wy == 0.f && y0 != iy && y1 != iy) continue;
+      f32x4 rowacc = {0, 0, 0, 0};
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        int x0, x1; float lx0, lx1;
+        lerp_coord(ox, sx, W, x0, x1, lx0, lx1);
+        if (x0 != ix && x1 != ix) continue;
+        const f32x4 g = *(const f32x4*)(b + ((size_t)oy * OW + ox) * lddy);
+        // keep the forward's grouping: contribution = ly * (lx * g)
+        if (x0 == ix) rowacc += lx0 * g;
+        if (x1 == ix) rowacc += lx1 * g;
+      }
+      if (y0 == iy) acc += ly0 * rowacc;
+      if (y1 == iy) acc += ly1 * rowacc;
+    }
+    *(f32x4*)(dx + ((size_t)(n * H + iy) * W + ix) * lddx + 4 * cq) = acc;
+  }
+}
+
+// ---------------------------------------------------------------- nearest x2
+__global__ __launch_bounds__(256) void nearest_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
+                                                          float* __restrict__ y, int ldy) {
+  const int OH = 2 * H, OW = 2 * W, CQ = C / 4;
+  const long long total = (long long)N * OH * OW * CQ;
+  GRID_STRIDE(i, total) {
+    const int cq = (int)(i % CQ); long long r = i / CQ;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH); const int n = (int)(r / OH);
+    *(f32x4*)(y + ((size_t)(n * OH + oy) * OW + ox) * ldy + 4 * cq) =
+        *(const f32x4*)(x + ((size_t)(n * H + (oy >> 1)) * W + (ox >> 1)) * ldx + 4 * cq);
+  }
+}
+__global__ __launch_bounds__(256) void nearest_bwd_kernel(const float* __restrict__ dy, int lddy, int N, int H, int W, int C,
+                                                          float* __restrict__ dx, int lddx) {
+  const int OW = 2 * W, CQ = C / 4;
+  const long long total = (long long)N * H * W * CQ;
+  GRID_STRIDE(i, total) {
+    const int cq = (int)(i % CQ); long long r = i / CQ;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H); const int n = (int)(r / H);
+    const float* b = dy + ((size_t)(n * 2 * H + 2 * iy) * OW + 2 * ix) * lddy + 4 * cq;
+    const f32x4 s = (*(const f32x4*)b + *(const f32x4*)(b + lddy)) + (*(const f32x4*)(b + (size_t)OW * lddy) + *(const f32x4*)(b + (size_t)(OW + 1) * lddy));
+    *(f32x4*)(dx + ((size_t)(n * H + iy) * W + ix) * lddx + 4 * cq) = s;
+  }
+}
+
+// ---------------------------------------------------------------- adaptive avg pool -> flat NCHW order
+__device__ __forceinline__ int bin_lo(int o, int in, int out) { return (o * in) / out; }
+__device__ __forceinline__ int bin_hi(int o, int in, int out) { return ((o + 1) * in + out - 1) / out; }
+
+__global__ __launch_bounds__(256) void avgpool_flat_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
+                                                               int O, float* __restrict__ y) {
+  const long long total = (long long)N * O * O * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C); long long r = i / C;
+    const int ox = (int)(r % O); r /= O;
+    const int oy = (int)(r % O); const int n = (int)(r / O);
+    const int y0 = bin_lo(oy, H, O), y1 = bin_hi(oy, H, O), x0 = bin_lo(ox, W, O), x1 = bin_hi(ox, W, O);
+    float s = 0.f;
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) s += x[((size_t)(n * H + yy) * W + xx) * ldx + c];
+    y[(size_t)n * C * O * O + (size_t)c * O * O + oy * O + ox] = s / (float)((y1 - y0) * (x1 - x0));
+  }
+}
+__global__ __launch_bounds__(256) void avgpool_flat_bwd_kernel(const float* __restrict__ dy, int N, int H, int W, int C, int O,
+                                                               float* __restrict__ dx, int lddx) {
+  const long long total = (long long)N * H * W * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C); long long r = i / C;
+    const int xx = (int)(r % W); r /= W;
+    const int yy = (int)(r % H); const int n = (int)(r / H);
+    float s = 0.f;
+    for (int oy = 0; oy < O; ++oy) {
+      const int y0 = bin_lo(oy, H, O), y1 = bin_hi(oy, H, O);
+      if (yy < y0 || yy >= y1) continue;
+      for (int ox = 0; ox < O; ++ox) {
+        const int x0 = bin_lo(ox, W, O), x1 = bin_hi(ox, W, O);
+        if (xx < x0 || xx >= x1) continue;
+        s += dy[(size_t)n * C * O * O + (size_t)c * O * O + oy * O + ox] / (float)((y1 - y0) * (x1 - x0));
+      }
+    }
+    dx[((size_t)(n * H + yy) * W + xx) * lddx + c] = s;
+  }
+}
+
+// ---------------------------------------------------------------- NCHW <-> NHWC(ld)
+// 32x32 LDS transpose per (n, 32 pixels, 32 channels) tile so both sides stay coalesced.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, int C, long long S, float* __restrict__ dst, int ld) {
+  // grid: x = pixel tiles of 64, y = n; threads: 64 pixels x 4 channel lanes; small C (3..) fast path
+  const long long p = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int n = blockIdx.y;
+  if (p >= S) return;
+  for (int c = threadIdx.x >> 6; c < ld; c += 4) {
+    const float v = c < C ? src[((size_t)n * C + c) * S + p] : 0.f;
+    dst[((size_t)n * S + p) * ld + c] = v;
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, int C, long long S, float* __restrict__ dst) {
+  const long long p = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int n = blockIdx.y;
+  if (p >= S) return;
+  for (int c = threadIdx.x >> 6; c < C; c += 4) dst[((size_t)n * C + c) * S + p] = src[((size_t)n * S + p) * ld + c];
+}
+
+#define REQ_Q(C, ...) SSG_REQUIRE((C) > 0 && (C) % 4 == 0, SSG_EINVAL, __VA_ARGS__)
+
+}  // namespace
+
+extern "C" int ssg_maxpool2x2_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, uint8_t* idx, void* stream) {
+  SSG_REQUIRE(x && y && idx && N > 0 && H >= 2 && W >= 2, SSG_EINVAL, "maxpool: bad args");
+  REQ_Q(C, "maxpool: C %% 4");
+  SSG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, SSG_EALIGN, "maxpool: strides");
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ldx, y, ldy, idx);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_maxpool2x2_bwd_f32(const float* dy, int lddy, const uint8_t* idx, int N, int H, int W, int C, float* dx, int lddx, void* stream) {
+  SSG_REQUIRE(dy && dx && idx && N > 0 && H % 2 == 0 && W % 2 == 0, SSG_EINVAL, "maxpool_bwd: needs even H, W");
+  REQ_Q(C, "maxpool_bwd: C %% 4");
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(scatter2x2_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, idx, N, H / 2, W / 2, C, dx, lddx);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_maxunpool2x2_fwd_f32(const float* x, int ldx, const uint8_t* idx, int N, int OH, int OW, int C, float* y, int ldy, void* stream) {
+  SSG_REQUIRE(x && y && idx && N > 0 && OH % 2 == 0 && OW % 2 == 0, SSG_EINVAL, "maxunpool: bad args");
+  REQ_Q(C, "maxunpool: C %% 4");
+  const long long total = (long long)N * (OH / 2) * (OW / 2) * (C / 4);
+  hipLaunchKernelGGL(scatter2x2_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, idx, N, OH / 2, OW / 2, C, y, ldy);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_maxunpool2x2_bwd_f32(const float* dy, int lddy, const uint8_t* idx, int N, int OH, int OW, int C, float* dx, int lddx, void* stream) {
+  SSG_REQUIRE(dy && dx && idx && N > 0 && OH % 2 == 0 && OW % 2 == 0, SSG_EINVAL, "maxunpool_bwd: bad args");
+  REQ_Q(C, "maxunpool_bwd: C %% 4");
+  const long long total = (long long)N * (OH / 2) * (OW / 2) * (C / 4);
+  hipLaunchKernelGGL(gather2x2_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, idx, N, OH / 2, OW / 2, C, dx, lddx);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_upsample2x_bilinear_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, void* stream) {
+  SSG_REQUIRE(x && y && N > 0 && H > 0 && W > 0, SSG_EINVAL, "bilinear: bad args");
+  REQ_Q(C, "bilinear: C %% 4");
+  const float sy = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f, sx = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+  const long long total = (long long)N * 4 * H * W * (C / 4);
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ldx, y, ldy, sy, sx);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_upsample2x_bilinear_bwd_f32(const float* dy, int lddy, int N, int H, int W, int C, float* dx, int lddx, void* stream) {
+  SSG_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0, SSG_EINVAL, "bilinear_bwd: bad args");
+  REQ_Q(C, "bilinear_bwd: C %% 4");
+  const float sy = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f, sx = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+  const long long total = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, N, H, W, C, dx, lddx, sy, sx);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_upsample2x_nearest_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, void* stream) {
+  SSG_REQUIRE(x && y && N > 0 && H > 0 && W > 0, SSG_EINVAL, "nearest: bad args");
+  REQ_Q(C, "nearest: C %% 4");
+  const long long total = (long long)N * 4 * H * W * (C / 4);
+  hipLaunchKernelGGL(nearest_fwd_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ldx, y, ldy);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_upsample2x_nearest_bwd_f32(const float* dy, int lddy, int N, int H, int W, int C, float* dx, int lddx, void* stream) {
+  SSG_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0, SSG_EINVAL, "nearest_bwd: bad args");
+  REQ_Q(C, "nearest_bwd: C %% 4");
+  const long long total = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(nearest_bwd_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, N, H, W, C, dx, lddx);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_adaptive_avgpool_flat_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, int OHW, float* y, void* stream) {
+  SSG_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && OHW > 0, SSG_EINVAL, "avgpool: bad args");
+  const long long total = (long long)N * OHW * OHW * C;
+  hipLaunchKernelGGL(avgpool_flat_fwd_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ldx, OHW, y);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_adaptive_avgpool_flat_bwd_f32(const float* dy, int N, int H, int W, int C, int OHW, float* dx, int lddx, void* stream) {
+  SSG_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && OHW > 0, SSG_EINVAL, "avgpool_bwd: bad args");
+  const long long total = (long long)N * H * W * C;
+  hipLaunchKernelGGL(avgpool_flat_bwd_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, N, H, W, C, OHW, dx, lddx);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_nchw_to_nhwc_f32(const float* src, int N, int C, int H, int W, float* dst, int ld, void* stream) {
+  SSG_REQUIRE(src && dst && N > 0 && C > 0 && ld >= C, SSG_EINVAL, "nchw_to_nhwc: bad args");
+  const long long S = (long long)H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)ssg_cdiv(S, 64), (unsigned)N), dim3(256), 0, (hipStream_t)stream, src, C, S, dst, ld);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_nhwc_to_nchw_f32(const float* src, int ld, int N, int C, int H, int W, float* dst, void* stream) {
+  SSG_REQUIRE(src && dst && N > 0 && C > 0 && ld >= C, SSG_EINVAL, "nhwc_to_nchw: bad args");
+  const long long S = (long long)H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)ssg_cdiv(S, 64), (unsigned)N), dim3(256), 0, (hipStream_t)stream, src, ld, C, S, dst);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}

@@ -1,0 +1,745 @@
+"""Autograd ops over the gfx950 C-ABI (include/ssunet_hip.h).  Every op here launches a
+hand-written HIP kernel; none falls back to a stock torch compute op, and all of them raise
+if the tensors are not on a HIP device or the shared library is not built.
+
+Tensor convention ("NHWC-with-stride"): an activation is a torch tensor of logical shape
+[N, C, H, W] whose memory is [N, H, W, ld] with ld = C rounded up to 4 (pad channels are
+zero).  For C % 4 == 0 this is exactly torch.channels_last, so tensors stay ordinary torch
+tensors at the nn.Module boundary while the kernels see coalesced channel rows.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvDesc, WgradDesc, call, ptr, stream_ptr
+
+__all__ = ['conv2d', 'batch_norm_act', 'max_pool2x2', 'max_unpool2x2', 'upsample2x_bilinear', 'upsample2x_nearest',
+           'spade_modulate', 'adaptive_avgpool_flat', 'linear', 'seg_loss', 'bce_with_logits_const', 'nan_to_zero_',
+           'to_nhwc', 'new_nhwc', 'bump_weight_epoch']
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+# ----------------------------------------------------------------------------- layout helpers
+def new_nhwc(n, c, h, w, device, ld=None, zero=False):
+    ld = pad4(c) if ld is None else ld
+    buf = (torch.zeros if zero else torch.empty)((n, h, w, ld), device=device, dtype=torch.float32)
+    return buf.permute(0, 3, 1, 2)[:, :c]
+
+
+def nhwc_ld(x):
+    """Pixel stride ld if x is NHWC-with-stride (and usable by the kernels), else None."""
+    if x.dim() != 4 or x.dtype != torch.float32:
+        return None
+    n, c, h, w = x.shape
+    s = x.stride()
+    if w > 1:
+        ld = s[3]
+    elif h > 1:
+        ld = s[2]
+    elif n > 1:
+        ld = s[0]
+    else:
+        ld = pad4(c)
+    if ld % 4 or ld < c or (c > 1 and s[1] != 1):
+        return None
+    if (w > 1 and s[3] != ld) or (h > 1 and s[2] != w * ld) or (n > 1 and s[0] != h * w * ld):
+        return None
+    if c % 4 and ld != pad4(c):          # padded tensors must be our own (zero pad lanes)
+        return None
+    if x.data_ptr() % 16:
+        return None
+    return ld
+
+
+def to_nhwc(x):
+    """Return x in NHWC-with-stride form (no copy if it already is)."""
+    _lib.require_gpu(x)
+    if nhwc_ld(x) is not None:
+        return x
+    if x.dtype != torch.float32:
+        raise TypeError('ssunet-gan_amd ops are fp32; got %s' % x.dtype)
+    src = x.detach()
+    if not src.is_contiguous():
+        src = src.contiguous()
+    n, c, h, w = src.shape
+    out = new_nhwc(n, c, h, w, x.device)
+    call('ssg_nchw_to_nhwc_f32', ptr(src), n, c, h, w, ptr(out), pad4(c), stream_ptr())
+    return out
+
+
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return to_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def as_nhwc(x):
+    """Differentiable layout normalisation used at module boundaries."""
+    if nhwc_ld(x) is not None:
+        return x
+    return _ToNHWC.apply(x) if x.requires_grad else to_nhwc(x)
+
+
+def _ld(x):
+    ld = nhwc_ld(x)
+    if ld is None:
+        raise _lib.HipLibraryError('internal: tensor is not NHWC-with-stride: shape %s stride %s' % (tuple(x.shape), x.stride()))
+    return ld
+
+
+def _ws(nbytes, device):
+    return torch.empty((max(int(nbytes), 16) + 15) // 16 * 2, dtype=torch.float64, device=device)
+
+
+# ----------------------------------------------------------------------------- weight packing cache
+_WEIGHT_EPOCH = [0]
+_PACK_CACHE = {}
+
+
+def bump_weight_epoch():
+    """Called by the fused optimizer (which writes parameters through raw pointers, invisible
+    to tensor version counters) to invalidate packed-weight caches."""
+    _WEIGHT_EPOCH[0] += 1
+    if len(_PACK_CACHE) > 4096:
+        _PACK_CACHE.clear()
+
+
+def _taps_fwd(kh, kw, pad):
+    return [(ky, kx, ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
+
+
+def _pack(weight, transpose, taps, cred_pad, c1_for_mode):
+    """Pack an OIHW weight for the given tap list; returns (tensor[R, Kp], Kp, kmode)."""
+    o, i, kh, kw = weight.shape
+    nt = len(taps)
+    kmode = 0 if (cred_pad % 16 == 0 and c1_for_mode % 16 == 0) else 1
+    kp = nt * cred_pad if kmode == 0 else (nt * cred_pad + 15) // 16 * 16
+    rows = i if transpose else o
+    key = (weight.data_ptr(), weight._version, _WEIGHT_EPOCH[0], transpose, tuple(taps), cred_pad, kmode)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit, kp, kmode
+    out = torch.empty((rows, kp), device=weight.device, dtype=torch.float32)
+    ky = (C.c_int * nt)(*[t[0] for t in taps])
+    kx = (C.c_int * nt)(*[t[1] for t in taps])
+    call('ssg_pack_weights_f32', ptr(weight), o, i, kh, kw, int(transpose), nt, ky, kx, kmode, cred_pad, kp, ptr(out), stream_ptr())
+    _PACK_CACHE[key] = out
+    return out, kp, kmode
+
+
+def _fill_taps(desc, taps):
+    desc.ntaps = len(taps)
+    for t, (_, _, dy, dx) in enumerate(taps):
+        desc.dy[t] = dy
+        desc.dx[t] = dx
+
+
+def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps, n, h, w, gh, gw, oh, ow,
+                 in_s, out_s, out_oy, out_ox, out, bnpart=None):
+    d = ConvDesc()
+    d.in1 = x1.data_ptr(); d.C1 = pad4(x1.shape[1]); d.ld1 = _ld(x1)
+    if x2 is not None:
+        d.in2 = x2.data_ptr(); d.C2 = pad4(x2.shape[1]); d.ld2 = _ld(x2)
+    else:
+        d.in2 = None; d.C2 = 0; d.ld2 = 0
+    d.N, d.H, d.W = n, h, w
+    d.w = wpk.data_ptr() + row0 * kp * 4; d.Kp = kp; d.kmode = kmode
+    d.bias = bias.data_ptr() if bias is not None else None
+    if res is not None:
+        d.res = res.data_ptr(); d.ldr = _ld(res)
+    else:
+        d.res = None; d.ldr = 0
+    d.out = out.data_ptr(); d.Cout = cout; d.ldo = _ld(out)
+    d.GH, d.GW, d.OH, d.OW = gh, gw, oh, ow
+    d.in_sy = d.in_sx = in_s
+    d.out_sy = d.out_sx = out_s
+    d.out_oy, d.out_ox = out_oy, out_ox
+    _fill_taps(d, taps)
+    d.act = act; d.slope = slope
+    d.bnpart = bnpart.data_ptr() if bnpart is not None else None
+    call('ssg_conv2d_igemm_f32', C.byref(d), stream_ptr())
+
+
+def _out_size(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=None):
+    o, i, kh, kw = weight.shape
+    n, c1, h, w = x1.shape
+    c2 = x2.shape[1] if x2 is not None else 0
+    if x2 is not None and c1 % 4:
+        raise ValueError('two-input conv needs C1 %% 4 == 0 (got %d)' % c1)
+    if c1 + c2 != i:
+        raise ValueError('conv: input channels %d+%d != weight in-channels %d' % (c1, c2, i))
+    cred_pad = pad4(c1) + pad4(c2)
+    taps = _taps_fwd(kh, kw, pad)
+    wpk, kp, kmode = _pack(weight, 0, taps, cred_pad, pad4(c1))
+    oh, ow = _out_size(h, kh, stride, pad), _out_size(w, kw, stride, pad)
+    if out is None:
+        out = new_nhwc(n, o, oh, ow, x1.device)
+    _conv_launch(x1, x2, wpk, kp, kmode, 0, o, bias, res, act, slope, taps, n, h, w, oh, ow, oh, ow, stride, 1, 0, 0, out)
+    return out
+
+
+def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None):
+    """Input gradient for input channels [c_lo, c_hi) -> NHWC tensor [N, c_hi-c_lo, h, w].
+    `res` (same shape) is added in the epilogue: gradient accumulation without an extra pass."""
+    o, i, kh, kw = weight.shape
+    n, _, oh, ow = dy.shape
+    cred_pad = pad4(o)
+    dx = new_nhwc(n, c_hi - c_lo, h, w, dy.device)
+    if stride == 1:
+        taps = [(ky, kx, pad - ky, pad - kx) for ky in range(kh) for kx in range(kw)]
+        wpk, kp, kmode = _pack(weight, 1, taps, cred_pad, cred_pad)
+        _conv_launch(dy, None, wpk, kp, kmode, c_lo, c_hi - c_lo, None, res, ACT_NONE, 0.0, taps, n, oh, ow, h, w, h, w, 1, 1, 0, 0, dx)
+        return dx
+    if res is not None:
+        raise NotImplementedError('strided dgrad with fused accumulation')
+    s = stride
+    classes = []
+    for py in range(s):
+        for px in range(s):
+            taps = [(ky, kx, (py + pad - ky) // s, (px + pad - kx) // s) for ky in range(kh) for kx in range(kw)
+                    if (py + pad - ky) % s == 0 and (px + pad - kx) % s == 0]
+            classes.append((py, px, taps))
+    if any(len(t) == 0 for _, _, t in classes):
+        dx.zero_()
+    for py, px, taps in classes:
+        gh, gw = (h - py + s - 1) // s, (w - px + s - 1) // s
+        if not taps or gh <= 0 or gw <= 0:
+            continue
+        wpk, kp, kmode = _pack(weight, 1, taps, cred_pad, cred_pad)
+        _conv_launch(dy, None, wpk, kp, kmode, c_lo, c_hi - c_lo, None, None, ACT_NONE, 0.0, taps, n, oh, ow, gh, gw, h, w, 1, s, py, px, dx)
+    return dx
+
+
+def _conv_wgrad_impl(x1, x2, dy, weight_shape, stride, pad):
+    o, i, kh, kw = weight_shape
+    n, c1, h, w = x1.shape
+    _, _, oh, ow = dy.shape
+    d = WgradDesc()
+    d.in1 = x1.data_ptr(); d.C1 = pad4(c1); d.ld1 = _ld(x1)
+    if x2 is not None:
+        d.in2 = x2.data_ptr(); d.C2 = pad4(x2.shape[1]); d.ld2 = _ld(x2)
+    else:
+        d.in2 = None; d.C2 = 0; d.ld2 = 0
+    d.N, d.H, d.W = n, h, w
+    d.dout = dy.data_ptr(); d.Cout = o; d.ldd = _ld(dy); d.GH, d.GW = oh, ow
+    d.in_sy = d.in_sx = stride
+    taps = _taps_fwd(kh, kw, pad)
+    _fill_taps(d, taps)
+    for t, (ky, kx, _, _) in enumerate(taps):
+        d.ky[t] = ky; d.kx[t] = kx
+    d.KH, d.KW, d.Cin_real = kh, kw, i
+    dw = torch.empty((o, i, kh, kw), device=dy.device, dtype=torch.float32)
+    d.dw_oihw = dw.data_ptr()
+    d.ws = None; d.ws_bytes = 0
+    nbytes = call('ssg_conv2d_wgrad_workspace_bytes', C.byref(d))
+    ws = _ws(nbytes, dy.device)
+    d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 8
+    call('ssg_conv2d_wgrad_f32', C.byref(d), stream_ptr())
+    return dw
+
+
+def _channel_sum(x, c):
+    n, _, h, w = x.shape
+    p = n * h * w
+    out = torch.empty(c, device=x.device, dtype=torch.float32)
+    ws = _ws(call('ssg_bn_workspace_bytes', p, c), x.device)
+    call('ssg_channel_sum_f32', ptr(x), p, c, _ld(x), ptr(out), ptr(ws), stream_ptr())
+    return out
+
+
+def _act_bwd(y, dy, act, slope):
+    n, c, h, w = y.shape
+    dx = new_nhwc(n, c, h, w, y.device)
+    call('ssg_act_bwd_f32', ptr(y), _ld(y), ptr(dy), _ld(dy), n * h * w, pad4(c), act, slope, ptr(dx), _ld(dx), stream_ptr())
+    return dx
+
+
+class _Conv2d(torch.autograd.Function):
+    """F.conv2d (+bias, +activation, optional second input = channel concat) on MFMA."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, stride, pad, act, slope):
+        x1 = to_nhwc(x1)
+        x2 = to_nhwc(x2) if x2 is not None else None
+        y = _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope)
+        ctx.cfg = (stride, pad, act, slope)
+        ctx.save_for_backward(x1, x2, weight, y if act != ACT_NONE else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x1, x2, weight, y = ctx.saved_tensors
+        stride, pad, act, slope = ctx.cfg
+        dy = to_nhwc(dy)
+        if act != ACT_NONE:
+            dy = _act_bwd(y, dy, act, slope)
+        n, c1, h, w = x1.shape
+        dx1 = dx2 = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx1 = _conv_dgrad_impl(dy, weight, stride, pad, h, w, 0, c1)
+        if x2 is not None and ctx.needs_input_grad[1]:
+            dx2 = _conv_dgrad_impl(dy, weight, stride, pad, h, w, c1, c1 + x2.shape[1])
+        if ctx.needs_input_grad[2]:
+            dw = _conv_wgrad_impl(x1, x2, dy, weight.shape, stride, pad)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = _channel_sum(dy, weight.shape[0])
+        return dx1, dx2, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, x2=None):
+    _lib.require_gpu(x)
+    return _Conv2d.apply(x, x2, weight, bias, int(stride), int(padding), int(act), float(slope))
+
+
+# ----------------------------------------------------------------------------- linear (as 1x1 conv over a 1 x N "image")
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        n, k = x.shape
+        o = weight.shape[0]
+        if k % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+            x = _pad_rows(x)
+        xi = x.as_strided((1, k, 1, n), (n * x.stride(0), 1, n * x.stride(0), x.stride(0)))
+        y = _conv_fwd_impl(xi, None, weight.view(o, k, 1, 1), bias, 1, 0, act, slope)      # [1, o, 1, n]
+        ld = _ld(y)
+        y2 = y.as_strided((n, o), (ld, 1))
+        ctx.save_for_backward(xi, weight, y if act != ACT_NONE else None)
+        ctx.cfg = (act, slope, n, k, o, bias is not None)
+        return y2
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy2):
+        xi, weight, y = ctx.saved_tensors
+        act, slope, n, k, o, has_bias = ctx.cfg
+        if dy2.stride(1) != 1 or dy2.stride(0) % 4 or dy2.stride(0) < pad4(o) or dy2.data_ptr() % 16 or (o % 4 and dy2.stride(0) != pad4(o)):
+            dy2 = _pad_rows(dy2)
+        ldd = dy2.stride(0)
+        dy = dy2.as_strided((1, o, 1, n), (n * ldd, 1, n * ldd, ldd))
+        if act != ACT_NONE:
+            dy = _act_bwd(y, dy, act, slope)
+        w4 = weight.view(o, k, 1, 1)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            d = _conv_dgrad_impl(dy, w4, 1, 0, 1, n, 0, k)
+            dx = d.as_strided((n, k), (_ld(d), 1))
+        if ctx.needs_input_grad[1]:
+            dw = _conv_wgrad_impl(xi, None, dy, (o, k, 1, 1), 1, 0).view(o, k)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sum(dy, o)
+        return dx, dw, db, None, None
+
+
+def _pad_rows(x):
+    """Copy a [n, k] matrix into a zero-padded [n, pad4(k)] buffer (tiny tensors only)."""
+    n, k = x.shape
+    buf = torch.zeros((n, pad4(k)), device=x.device, dtype=torch.float32)
+    xi = x.detach().contiguous().view(n, k, 1, 1)
+    call('ssg_nchw_to_nhwc_f32', ptr(xi), n, k, 1, 1, ptr(buf), pad4(k), stream_ptr())
+    return buf[:, :k]
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
+    _lib.require_gpu(x)
+    return _Linear.apply(x, weight, bias, int(act), float(slope))
+
+
+# ----------------------------------------------------------------------------- batch norm (+residual, +activation)
+def _allreduce_sums(sums, group):
+    if group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        return dist.get_world_size(group)
+    return 1
+
+
+def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group):
+    """stats -> (all-reduce) -> finalize -> apply.  Returns (y, stats[4,C], world)."""
+    n, c, h, w = x.shape
+    if c % 4:
+        raise ValueError('batch_norm: C %% 4 != 0 unsupported (C=%d)' % c)
+    p = n * h * w
+    dev = x.device
+    ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
+    sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+    call('ssg_bn_stats_f32', ptr(x), p, c, _ld(x), ptr(sums), ptr(ws), stream_ptr())
+    world = _allreduce_sums(sums, group)
+    stats = torch.empty((4, c), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
+    call('ssg_bn_finalize_f32', ptr(sums), float(p * world), c, ptr(weight), ptr(bias), eps, momentum, var_mode,
+         ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), stream_ptr())
+    y = new_nhwc(n, c, h, w, dev)
+    call('ssg_bn_apply_f32', ptr(x), p, c, _ld(x), ptr(stats[2]), ptr(stats[3]), ptr(res), _ld(res) if res is not None else 0,
+         act, slope, ptr(y), _ld(y), stream_ptr())
+    return y, stats, world
+
+
+def _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, want_dres, want_dx=True):
+    """Returns (dx, dres, dweight, dbias).  y is only needed when act != none (activation mask)."""
+    n, c, h, w = x.shape
+    p = n * h * w
+    dev = x.device
+    ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
+    sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+    call('ssg_bn_bwd_reduce_f32', ptr(x), ptr(y), ptr(dy), p, c, _ld(x), _ld(y) if y is not None else 0, _ld(dy),
+         ptr(stats[0]), ptr(stats[1]), act, slope, ptr(sums), ptr(ws), stream_ptr())
+    # local (un-reduced) sums are this rank's weight/bias gradients; data-parallel all-reduces them later
+    synced = group is not None and world > 1
+    local = sums.clone() if synced else sums
+    _allreduce_sums(sums, group)
+    dwb = torch.empty((2, c), dtype=torch.float32, device=dev)
+    dx = new_nhwc(n, c, h, w, dev) if want_dx else None
+    dres = new_nhwc(n, c, h, w, dev) if want_dres else None
+    call('ssg_bn_bwd_apply_f32', ptr(x), ptr(y), ptr(dy), p, c, _ld(x), _ld(y) if y is not None else 0, _ld(dy),
+         ptr(stats[0]), ptr(stats[1]), ptr(weight), ptr(sums), float(p * world), act, slope,
+         ptr(dx), _ld(dx) if dx is not None else 0, ptr(dres), _ld(dres) if dres is not None else 0,
+         ptr(dwb[0]), ptr(dwb[1]), stream_ptr())
+    if synced:
+        dwb = torch.stack([local[c:], local[:c]]).float()
+    return dx, dres, dwb[0], dwb[1]
+
+
+class _BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group):
+        x = to_nhwc(x)
+        res = to_nhwc(res) if res is not None else None
+        y, stats, world = _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group)
+        ctx.save_for_backward(x, y if act != ACT_NONE else None, weight, stats)
+        ctx.cfg = (act, slope, group, world, res is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, y, weight, stats = ctx.saved_tensors
+        act, slope, group, world, has_res = ctx.cfg
+        dy = to_nhwc(dy)
+        dx, dres, dw, db = _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, has_res and ctx.needs_input_grad[5])
+        return dx, dw, db, None, None, dres, None, None, None, None, None, None
+
+
+class _AffineAct(torch.autograd.Function):
+    """Eval-mode BN: y = x*scale + shift (+res) -> act with constant scale/shift."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, res, act, slope):
+        x = to_nhwc(x)
+        res = to_nhwc(res) if res is not None else None
+        n, c, h, w = x.shape
+        y = new_nhwc(n, c, h, w, x.device)
+        call('ssg_bn_apply_f32', ptr(x), n * h * w, c, _ld(x), ptr(scale), ptr(shift), ptr(res), _ld(res) if res is not None else 0,
+             act, slope, ptr(y), _ld(y), stream_ptr())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        raise NotImplementedError('eval-mode batch norm is inference-only in ssunet-gan_amd')
+
+
+def batch_norm_act(x, bn, res=None, act=ACT_NONE, slope=0.0, group=None, var_mode=None):
+    """nn.BatchNorm2d `bn` (any _BatchNorm holding weight/bias/running stats) + residual + activation."""
+    _lib.require_gpu(x)
+    if bn.training or not bn.track_running_stats:
+        if bn.momentum is None:
+            raise NotImplementedError('cumulative-average batch norm (momentum=None)')
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        if var_mode is None:
+            var_mode = 1 if group is not None else 0
+        return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                   bn.running_var if bn.track_running_stats else None, res, float(bn.eps), float(bn.momentum),
+                                   int(act), float(slope), int(var_mode), group)
+    with torch.no_grad():
+        scale = torch.rsqrt(bn.running_var + bn.eps)
+        if bn.weight is not None:
+            scale = scale * bn.weight
+        shift = -bn.running_mean * scale
+        if bn.bias is not None:
+            shift = shift + bn.bias
+    return _AffineAct.apply(x, scale.contiguous(), shift.contiguous(), res, int(act), float(slope))
+
+
+# ----------------------------------------------------------------------------- pool / unpool / upsample
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        if c % 4 or h % 2 or w % 2:
+            raise ValueError('max_pool2x2: needs C %% 4 == 0 and even H, W (got %s)' % (tuple(x.shape),))
+        oh, ow = h // 2, w // 2
+        y = new_nhwc(n, c, oh, ow, x.device)
+        idx = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device)
+        call('ssg_maxpool2x2_fwd_f32', ptr(x), n, h, w, c, _ld(x), ptr(y), _ld(y), ptr(idx), stream_ptr())
+        ctx.save_for_backward(idx)
+        ctx.hw = (h, w)
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy, _):
+        (idx,) = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        n, c, oh, ow = dy.shape
+        h, w = ctx.hw
+        dx = new_nhwc(n, c, h, w, dy.device)
+        call('ssg_maxpool2x2_bwd_f32', ptr(dy), _ld(dy), ptr(idx), n, h, w, c, ptr(dx), _ld(dx), stream_ptr())
+        return dx
+
+
+def max_pool2x2(x):
+    """nn.MaxPool2d(2, 2, return_indices=True): returns (y, idx) with idx the 1-byte window argmax."""
+    _lib.require_gpu(x)
+    return _MaxPool.apply(x)
+
+
+class _MaxUnpool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        if tuple(idx.shape) != (n, h, w, c) or idx.dtype != torch.uint8:
+            raise ValueError('max_unpool2x2: indices %s do not match input %s' % (tuple(idx.shape), tuple(x.shape)))
+        y = new_nhwc(n, c, 2 * h, 2 * w, x.device)
+        call('ssg_maxunpool2x2_fwd_f32', ptr(x), _ld(x), ptr(idx), n, 2 * h, 2 * w, c, ptr(y), _ld(y), stream_ptr())
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        n, c, oh, ow = dy.shape
+        dx = new_nhwc(n, c, oh // 2, ow // 2, dy.device)
+        call('ssg_maxunpool2x2_bwd_f32', ptr(dy), _ld(dy), ptr(idx), n, oh, ow, c, ptr(dx), _ld(dx), stream_ptr())
+        return dx, None
+
+
+def max_unpool2x2(x, idx):
+    _lib.require_gpu(x)
+    return _MaxUnpool.apply(x, idx)
+
+
+def _make_upsample(fwd_name, bwd_name):
+    class _Up(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            x = to_nhwc(x)
+            n, c, h, w = x.shape
+            if c % 4:
+                raise ValueError('upsample2x: C %% 4 != 0')
+            y = new_nhwc(n, c, 2 * h, 2 * w, x.device)
+            call(fwd_name, ptr(x), n, h, w, c, _ld(x), ptr(y), _ld(y), stream_ptr())
+            return y
+
+        @staticmethod
+        @torch.autograd.function.once_differentiable
+        def backward(ctx, dy):
+            dy = to_nhwc(dy)
+            n, c, oh, ow = dy.shape
+            dx = new_nhwc(n, c, oh // 2, ow // 2, dy.device)
+            call(bwd_name, ptr(dy), _ld(dy), n, oh // 2, ow // 2, c, ptr(dx), _ld(dx), stream_ptr())
+            return dx
+    return _Up
+
+
+_BilinearUp = _make_upsample('ssg_upsample2x_bilinear_fwd_f32', 'ssg_upsample2x_bilinear_bwd_f32')
+_NearestUp = _make_upsample('ssg_upsample2x_nearest_fwd_f32', 'ssg_upsample2x_nearest_bwd_f32')
+
+
+def upsample2x_bilinear(x):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)."""
+    _lib.require_gpu(x)
+    return _BilinearUp.apply(x)
+
+
+def upsample2x_nearest(x):
+    """nn.Upsample(scale_factor=2) (nearest)."""
+    _lib.require_gpu(x)
+    return _NearestUp.apply(x)
+
+
+class _AvgPoolFlat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, o):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = torch.empty((n, c * o * o), dtype=torch.float32, device=x.device)
+        call('ssg_adaptive_avgpool_flat_fwd_f32', ptr(x), n, h, w, c, _ld(x), o, ptr(y), stream_ptr())
+        ctx.cfg = (n, c, h, w, o)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        n, c, h, w, o = ctx.cfg
+        dy = dy.contiguous()
+        dx = new_nhwc(n, c, h, w, dy.device, zero=(c % 4 != 0))
+        call('ssg_adaptive_avgpool_flat_bwd_f32', ptr(dy), n, h, w, c, o, ptr(dx), _ld(dx), stream_ptr())
+        return dx, None
+
+
+def adaptive_avgpool_flat(x, o=6):
+    """nn.AdaptiveAvgPool2d((o, o)) followed by .view(N, -1) in NCHW order."""
+    _lib.require_gpu(x)
+    return _AvgPoolFlat.apply(x, int(o))
+
+
+# ----------------------------------------------------------------------------- SPADE modulate
+class _SpadeModulate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gb):
+        x = to_nhwc(x); gb = to_nhwc(gb)
+        n, c, h, w = x.shape
+        if c % 4 or gb.shape[1] != 2 * c:
+            raise ValueError('spade_modulate: x has %d channels, gamma|beta has %d' % (c, gb.shape[1]))
+        y = new_nhwc(n, c, h, w, x.device)
+        call('ssg_spade_modulate_fwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), n * h * w, c, ptr(y), _ld(y), stream_ptr())
+        ctx.save_for_backward(x, gb)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, gb = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        n, c, h, w = x.shape
+        dx = new_nhwc(n, c, h, w, x.device)
+        dgb = new_nhwc(n, 2 * c, h, w, x.device)
+        call('ssg_spade_modulate_bwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), ptr(dy), _ld(dy), n * h * w, c,
+             ptr(dx), _ld(dx), ptr(dgb), _ld(dgb), stream_ptr())
+        return dx, dgb
+
+
+def spade_modulate(x, gb):
+    """out = x*(1+gamma)+beta with gamma = gb[:, :C], beta = gb[:, C:] (normalization.py:120)."""
+    _lib.require_gpu(x)
+    return _SpadeModulate.apply(x, gb)
+
+
+# ----------------------------------------------------------------------------- losses
+class _SegLoss(torch.autograd.Function):
+    """Fused BCEDiceLoss + MSELoss + IoU/Dice metrics.  Returns a float32[8] tensor `res`
+    (layout in include/ssunet_hip.h); gradients flow from res[0] (BCEDice) and res[1] (MSE)."""
+
+    @staticmethod
+    def forward(ctx, x, t, mc0):
+        x = to_nhwc(x); t = to_nhwc(t)
+        n, c, h, w = x.shape
+        s = h * w
+        dev = x.device
+        res = torch.empty(8, dtype=torch.float32, device=dev)
+        stats = torch.empty(3 * n + 5, dtype=torch.float64, device=dev)
+        ws = _ws(call('ssg_seg_loss_workspace_bytes', n, s, c), dev)
+        call('ssg_seg_loss_fwd_f32', ptr(x), _ld(x), ptr(t), _ld(t), n, s, c, mc0, ptr(res), ptr(stats), ptr(ws), stream_ptr())
+        ctx.save_for_backward(x, t, res, stats)
+        ctx.mark_non_differentiable(stats)
+        return res, stats
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g, _):
+        x, t, res, stats = ctx.saved_tensors
+        n, c, h, w = x.shape
+        g = g.contiguous()
+        dx = new_nhwc(n, c, h, w, x.device)
+        call('ssg_seg_loss_bwd_f32', ptr(x), _ld(x), ptr(t), _ld(t), n, h * w, c, ptr(res), ptr(stats),
+             C.c_void_p(g.data_ptr()), C.c_void_p(g.data_ptr() + 4), ptr(dx), _ld(dx), stream_ptr())
+        return dx, None, None
+
+
+def seg_loss(logits, target, metric_first_channel=1, with_sums=False):
+    """Fused loss/metric pass.  Returns res (float32[8]); with_sums=True also returns the fp64[5]
+    metric partial sums (for cross-rank reduction of IoU/Dice)."""
+    _lib.require_gpu(logits)
+    res, stats = _SegLoss.apply(logits, target, int(metric_first_channel))
+    if with_sums:
+        return res, stats[-5:]
+    return res
+
+
+class _BCEConst(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, label):
+        n = x.numel()
+        if x.dim() != 2 or x.shape[1] != 1:
+            raise ValueError('bce_with_logits_const expects [N, 1] logits')
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        call('ssg_bce_logits_const_fwd_f32', ptr(x), n, x.stride(0), label, ptr(loss), stream_ptr())
+        ctx.save_for_backward(x)
+        ctx.label = label
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        n = x.shape[0]
+        buf = torch.empty((n, 4), dtype=torch.float32, device=x.device)
+        g = g.contiguous()
+        call('ssg_bce_logits_const_bwd_f32', ptr(x), n, x.stride(0), ctx.label, ptr(g), ptr(buf), 4, stream_ptr())
+        return buf[:, :1], None
+
+
+def bce_with_logits_const(x, label):
+    """nn.BCEWithLogitsLoss()(x, full_like(x, label)) for x of shape [N, 1]."""
+    _lib.require_gpu(x)
+    return _BCEConst.apply(x, float(label))
+
+
+class _NanToZero(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ld = nhwc_ld(x) if x.dim() == 4 else None
+        if ld is not None:                          # operate on the whole padded buffer
+            n, c, h, w = x.shape
+            dense = x.as_strided((n * h * w * ld,), (1,))
+        elif x.is_contiguous():
+            dense = x.view(-1)
+        else:
+            raise ValueError('nan_to_zero_: unsupported layout (stride %s)' % (x.stride(),))
+        mask = torch.empty(dense.numel(), dtype=torch.uint8, device=x.device)
+        call('ssg_nan_to_zero_f32', ptr(dense), dense.numel(), ptr(mask), stream_ptr())
+        ctx.save_for_backward(mask)
+        ctx.nhwc = ld is not None
+        ctx.mark_dirty(x)
+        return x
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        if ctx.nhwc:
+            g = to_nhwc(g)
+            n, c, h, w = g.shape
+            ld = _ld(g)
+            out = new_nhwc(n, c, h, w, g.device, ld=ld)
+            call('ssg_mask_zero_f32', ptr(g), ptr(mask), n * h * w * ld, ptr(out), stream_ptr())
+            return out
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        call('ssg_mask_zero_f32', ptr(g), ptr(mask), g.numel(), ptr(out), stream_ptr())
+        return out
+
+
+def nan_to_zero_(x):
+    """x[isnan(x)] = 0 in place, differentiable (train_seg_gan.py:190)."""
+    _lib.require_gpu(x)
+    return _NanToZero.apply(x)

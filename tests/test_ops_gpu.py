@@ -1,0 +1,259 @@
+"""Per-op parity of the HIP kernels (through the C-ABI) against plain torch fp32 ops on the CPU.
+Tolerances: fp32 MFMA accumulates k-ordered fmaf chains; the CPU reference sums in another
+order, so conv outputs are compared with atol = 2e-5 * sqrt(K) * scale."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol, atol, what=''):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, '%s: max err %.3e (ref max %.3e, tol %.3e)' % (what, err, ref, atol + rtol * ref)
+
+
+CONV_CASES = [
+    # n, cin, cout, h, w, k, stride, pad, bias
+    (2, 16, 32, 20, 24, 3, 1, 1, False),
+    (1, 64, 64, 32, 32, 3, 1, 1, False),
+    (2, 3, 64, 18, 18, 3, 1, 1, False),      # first layer: Cin = 3 (padded to 4)
+    (2, 64, 3, 16, 16, 3, 1, 1, True),       # SPADE x2map: Cout = 3
+    (2, 3, 4, 16, 16, 3, 1, 1, True),        # SPADE shared: 3 -> 4
+    (2, 24, 384, 8, 8, 3, 1, 1, True),       # SPADE gamma: h=24 -> 384 (kmode 1, Cin % 16 != 0)
+    (1, 128, 160, 9, 11, 3, 1, 1, False),    # ragged spatial size, Cout not a tile multiple
+    (2, 32, 48, 16, 16, 1, 1, 0, False),     # 1x1
+    (2, 64, 3, 16, 16, 1, 1, 0, True),       # final 1x1 + bias
+    (2, 16, 16, 16, 16, 3, 2, 1, True),      # discriminator stride 2
+    (2, 32, 32, 15, 17, 3, 2, 1, True),      # stride 2 on odd sizes
+    (1, 256, 256, 16, 16, 3, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_fwd_bwd(pkg, dev, case):
+    n, cin, cout, h, w, k, s, p, bias = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) if bias else None
+    xr = x.clone().requires_grad_(True); wr = wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, s, p)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xd = x.to(dev).requires_grad_(True); wd = wt.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    yd = pkg.ops.conv2d(xd, wd, bd, s, p)
+    assert tuple(yd.shape) == tuple(yr.shape)
+    yd.backward(dy.to(dev))
+    kk = cin * k * k
+    _close(yd, yr, 1e-5, 2e-6 * math.sqrt(kk), 'conv fwd')
+    _close(xd.grad, xr.grad, 1e-5, 2e-6 * math.sqrt(cout * k * k), 'conv dgrad')
+    _close(wd.grad, wr.grad, 2e-5, 2e-6 * math.sqrt(n * h * w), 'conv wgrad')
+    if bias:
+        _close(bd.grad, br.grad, 2e-5, 1e-5, 'conv bias grad')
+
+
+def test_conv2d_concat_and_act(pkg, dev):
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.randn(2, 32, 12, 12, generator=g); x2 = torch.randn(2, 16, 12, 12, generator=g)
+    wt = torch.randn(40, 48, 3, 3, generator=g) / 20
+    r = [t.clone().requires_grad_(True) for t in (x1, x2, wt)]
+    yr = F.leaky_relu(F.conv2d(torch.cat([r[0], r[1]], 1), r[2], None, 1, 1), 0.2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    d = [t.to(dev).requires_grad_(True) for t in (x1, x2, wt)]
+    yd = pkg.ops.conv2d(d[0], d[2], None, 1, 1, act=pkg._lib.ACT_LRELU, slope=0.2, x2=d[1])
+    yd.backward(dy.to(dev))
+    _close(yd, yr, 1e-5, 5e-5, 'concat conv')
+    for a, b, nm in zip(d, r, ('dx1', 'dx2', 'dw')):
+        _close(a.grad, b.grad, 2e-5, 5e-5, nm)
+
+
+@pytest.mark.parametrize('shape,act,res', [((2, 16, 10, 12), 'relu', True), ((3, 64, 8, 8), 'lrelu', False),
+                                           ((1, 384, 4, 4), 'none', False), ((2, 8, 33, 17), 'relu', False)])
+def test_batch_norm_act(pkg, dev, shape, act, res):
+    g = torch.Generator().manual_seed(5)
+    n, c, h, w = shape
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    rr = torch.randn(shape, generator=g) if res else None
+    bn_r = torch.nn.BatchNorm2d(c); bn_d = torch.nn.BatchNorm2d(c).to(dev)
+    with torch.no_grad():
+        bn_r.weight.copy_(torch.rand(c, generator=g) + 0.5); bn_r.bias.copy_(torch.randn(c, generator=g))
+        bn_d.weight.copy_(bn_r.weight); bn_d.bias.copy_(bn_r.bias)
+    xr = x.clone().requires_grad_(True); rref = rr.clone().requires_grad_(True) if res else None
+    y = bn_r(xr)
+    if res:
+        y = y + rref
+    y = {'relu': F.relu, 'lrelu': lambda t: F.leaky_relu(t, 0.2), 'none': lambda t: t}[act](y)
+    dy = torch.randn(shape, generator=g)
+    y.backward(dy)
+    xd = x.to(dev).requires_grad_(True); rd = rr.to(dev).requires_grad_(True) if res else None
+    code = {'relu': pkg._lib.ACT_RELU, 'lrelu': pkg._lib.ACT_LRELU, 'none': pkg._lib.ACT_NONE}[act]
+    yd = pkg.ops.batch_norm_act(xd, bn_d, res=rd, act=code, slope=0.2)
+    yd.backward(dy.to(dev))
+    _close(yd, y, 1e-5, 1e-5, 'bn fwd')
+    _close(xd.grad, xr.grad, 1e-4, 2e-5, 'bn dx')
+    _close(bn_d.weight.grad, bn_r.weight.grad, 1e-4, 1e-4, 'bn dweight')
+    _close(bn_d.bias.grad, bn_r.bias.grad, 1e-4, 1e-4, 'bn dbias')
+    _close(bn_d.running_mean, bn_r.running_mean, 1e-5, 1e-6, 'running_mean')
+    _close(bn_d.running_var, bn_r.running_var, 1e-5, 1e-6, 'running_var')
+    assert int(bn_d.num_batches_tracked) == 1
+    if res:
+        _close(rd.grad, rref.grad, 1e-6, 1e-6, 'bn dres')
+
+
+def test_pool_unpool(pkg, dev):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 8, 12, 16, generator=g)
+    x[0, 0, 0, 0] = x[0, 0, 0, 1] = 5.0                  # a tie: first in scan order must win
+    xr = x.clone().requires_grad_(True)
+    yr, ir = F.max_pool2d(xr, 2, 2, return_indices=True)
+    z = torch.randn(yr.shape, generator=g).requires_grad_(True)
+    ur = F.max_unpool2d(z, ir, 2, 2)
+    dy = torch.randn(yr.shape, generator=g); du = torch.randn(ur.shape, generator=g)
+    yr.backward(dy); ur.backward(du)
+    xd = x.to(dev).requires_grad_(True)
+    yd, idx = pkg.ops.max_pool2x2(xd)
+    zd = z.detach().to(dev).requires_grad_(True)
+    ud = pkg.ops.max_unpool2x2(zd, idx)
+    yd.backward(dy.to(dev)); ud.backward(du.to(dev))
+    _close(yd, yr, 0, 0, 'pool'); _close(xd.grad, xr.grad, 0, 0, 'pool bwd')
+    _close(ud, ur, 0, 0, 'unpool'); _close(zd.grad, z.grad, 0, 0, 'unpool bwd')
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 5, 7), (1, 16, 16, 16), (2, 4, 1, 3)])
+def test_upsample(pkg, dev, shape):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(shape, generator=g)
+    for mode, fn in (('bilinear', pkg.ops.upsample2x_bilinear), ('nearest', pkg.ops.upsample2x_nearest)):
+        xr = x.clone().requires_grad_(True)
+        kw = dict(align_corners=True) if mode == 'bilinear' else {}
+        yr = F.interpolate(xr, scale_factor=2, mode=mode, **kw)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        xd = x.to(dev).requires_grad_(True)
+        yd = fn(xd)
+        yd.backward(dy.to(dev))
+        _close(yd, yr, 1e-6, 1e-6, mode + ' fwd')
+        _close(xd.grad, xr.grad, 1e-5, 2e-6, mode + ' bwd')
+
+
+@pytest.mark.parametrize('hw', [(12, 12), (6, 6), (2, 2), (7, 9), (32, 32)])
+def test_adaptive_avgpool_flat(pkg, dev, hw):
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 8, *hw, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.adaptive_avg_pool2d(xr, (6, 6)).view(2, -1)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xd = x.to(dev).requires_grad_(True)
+    yd = pkg.ops.adaptive_avgpool_flat(xd, 6)
+    yd.backward(dy.to(dev))
+    _close(yd, yr, 1e-6, 1e-6, 'avgpool'); _close(xd.grad, xr.grad, 1e-6, 1e-6, 'avgpool bwd')
+
+
+@pytest.mark.parametrize('n,k,o,act', [(2, 64, 32, True), (5, 288, 1024, True), (3, 1024, 1, False), (16, 48, 20, False)])
+def test_linear(pkg, dev, n, k, o, act):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, k, generator=g); wt = torch.randn(o, k, generator=g) / math.sqrt(k); b = torch.randn(o, generator=g)
+    r = [t.clone().requires_grad_(True) for t in (x, wt, b)]
+    yr = F.linear(*r)
+    if act:
+        yr = F.leaky_relu(yr, 0.2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    d = [t.to(dev).requires_grad_(True) for t in (x, wt, b)]
+    yd = pkg.ops.linear(d[0], d[1], d[2], act=pkg._lib.ACT_LRELU if act else 0, slope=0.2)
+    yd.backward(dy.to(dev))
+    _close(yd, yr, 1e-5, 1e-5, 'linear')
+    for a, bb, nm in zip(d, r, ('dx', 'dw', 'db')):
+        _close(a.grad, bb.grad, 2e-5, 2e-5, 'linear ' + nm)
+
+
+def test_spade_modulate(pkg, dev):
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 8, 6, 6, generator=g); gb = torch.randn(2, 16, 6, 6, generator=g)
+    xr = x.clone().requires_grad_(True); gr = gb.clone().requires_grad_(True)
+    yr = xr * (1 + gr[:, :8]) + gr[:, 8:]
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xd = x.to(dev).requires_grad_(True); gd = gb.to(dev).requires_grad_(True)
+    yd = pkg.ops.spade_modulate(xd, gd)
+    yd.backward(dy.to(dev))
+    _close(yd, yr, 1e-6, 1e-6, 'modulate'); _close(xd.grad, xr.grad, 1e-6, 1e-6, 'dx'); _close(gd.grad, gr.grad, 1e-6, 1e-6, 'dgb')
+
+
+def test_seg_loss_vs_oracle(pkg, dev):
+    from oracle import seg_gan_cpu as O
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 3, 20, 24, generator=g) * 3
+    t = (torch.rand(3, 3, 20, 24, generator=g) > 0.5).float()
+    xr = x.clone().requires_grad_(True)
+    lr = O.bce_dice_loss(xr, t); mr = F.mse_loss(xr, t)
+    (lr + 0.3 * mr).backward()
+    xd = x.to(dev).requires_grad_(True)
+    res = pkg.ops.seg_loss(xd, t.to(dev), 1)
+    (res[0] + 0.3 * res[1]).backward()
+    assert abs(res[0].item() - lr.item()) < 1e-5 and abs(res[1].item() - mr.item()) < 1e-5
+    assert abs(res[2].item() - O.stable_bce(x, t).item()) < 1e-5
+    assert abs(res[4].item() - O.iou_score(x[:, 1:].clone(), t[:, 1:].clone())) < 1e-6
+    assert abs(res[5].item() - O.dice_coef(x[:, 1:].clone(), t[:, 1:].clone())) < 1e-5
+    _close(xd.grad, xr.grad, 1e-4, 1e-8, 'seg loss grad')
+    # NaN handling: isnan -> 0 in place, gradient masked (train_seg_gan.py:190)
+    y = x.clone(); y[0, 0, 0, 0] = float('nan')
+    yd = y.to(dev).requires_grad_(True)
+    z = pkg.ops.nan_to_zero_(yd * 1.0)
+    assert z[0, 0, 0, 0].item() == 0.0 and not torch.isnan(z).any()
+    z.sum().backward()
+    assert yd.grad[0, 0, 0, 0].item() == 0.0 and yd.grad[0, 0, 0, 1].item() == 1.0
+
+
+def test_bce_const(pkg, dev):
+    x = torch.tensor([[0.3], [-2.0], [4.0], [0.0]])
+    for label in (0.0, 1.0):
+        xr = x.clone().requires_grad_(True)
+        lr = F.binary_cross_entropy_with_logits(xr, torch.full_like(xr, label)); lr.backward()
+        xd = x.to(dev).requires_grad_(True)
+        ld = pkg.ops.bce_with_logits_const(xd, label); ld.backward()
+        assert abs(ld.item() - lr.item()) < 1e-6
+        _close(xd.grad, xr.grad, 1e-5, 1e-7, 'bce grad')
+
+
+def test_clip_adam_matches_torch(pkg, dev):
+    g = torch.Generator().manual_seed(12)
+    shapes = [(64, 3, 3, 3), (5,), (1000, 37), (4097,)]
+    pr = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    pd = [p.detach().clone().to(dev).requires_grad_(True) for p in pr]
+    o_r = torch.optim.Adam(pr, lr=2e-3); o_d = torch.optim.Adam(pd, lr=2e-3)
+    for it in range(3):
+        for a, b in zip(pr, pd):
+            gr = torch.randn(a.shape, generator=g) * 2
+            a.grad = gr.clone(); b.grad = gr.clone().to(dev)
+        for a in pr:
+            a.grad.clamp_(-0.8, 0.8)
+        o_r.step()
+        pkg.optim.clip_adam_step(o_d, 0.8)
+        for a, b in zip(pr, pd):
+            _close(b, a, 1e-6, 1e-7, 'adam param it%d' % it)
+            _close(b.grad, a.grad, 0, 0, 'clamped grad')
+    assert float(o_d.state[pd[0]]['step']) == 3.0
+    pkg.srgan_utils.clip_gradient(o_d, 0.1)
+    assert pd[2].grad.abs().max().item() <= 0.1 + 1e-7
+
+
+def test_layout_roundtrip_and_errors(pkg, dev):
+    x = torch.randn(2, 3, 5, 7)
+    y = pkg.ops.to_nhwc(x.to(dev))
+    assert y.stride() == (5 * 7 * 4, 1, 7 * 4, 4)
+    assert torch.equal(y.cpu(), x)
+    with pytest.raises(RuntimeError):
+        pkg.ops.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 3, 3), None, 1, 1)      # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        pkg.ops.conv2d(torch.randn(1, 4, 4, 4).to(dev), torch.randn(4, 8, 3, 3).to(dev), None, 1, 1)
