@@ -46,7 +46,9 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
   const bool cok = cq < CQ;
   const long long p0 = (long long)blockIdx.x * rows_per_part;
   long long p1 = p0 + rows_per_part; if (p1 > P) p1 = P;
-  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  // fp64 accumulators: var = E[x^2] - mean^2 cancels catastrophically in fp32 for channels whose
+  // variance is far below mean^2 (deep layers with few pixels); x*x is exact in fp64.
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
   if (MODE == 1 && cok) {
 #pragma unroll
@@ -55,16 +57,24 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
   if (cok) {
     for (long long p = p0 + pr; p < p1; p += PR) {
       const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
-      if (MODE == 0) { s1 += xv; s2 += xv * xv; }
-      else if (MODE == 2) { s1 += xv; }
-      else {
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const double v = (double)xv[e]; s1[e] += v; s2[e] += v * v; }
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[e] += (double)xv[e];
+      } else {
         f32x4 g = *(const f32x4*)(dy + p * lddy + 4 * cq);
         if (act != SSG_ACT_NONE) {
           const f32x4 yv = *(const f32x4*)(y + p * ldy + 4 * cq);
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) g[e] *= (act == SSG_ACT_RELU ? 0.f : slope);
         }
-        s1 += g; s2 += g * ((xv - mu) * is);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double xh = ((double)xv[e] - (double)mu[e]) * (double)is[e];
+          s1[e] += (double)g[e]; s2[e] += (double)g[e] * xh;
+        }
       }
     }
   }
@@ -159,14 +169,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     if (dx) {
       const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
       f32x4 o;
+      // fp64 arithmetic, as ATen's CPU batch-norm backward (accscalar = double for float tensors):
+      // g - mean(g) - xhat*mean(g*xhat) cancels heavily, and an fp32-rounded per-channel constant
+      // would add the SAME error to every pixel (a coherent bias that the next dgrad/bias-grad
+      // sums amplify).  The kernel is HBM-bound; fp64 VALU work is free here.
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int c = 4 * cq + e;
-        const float is = invstd[c];
-        const float xh = (xv[e] - mean[c]) * is;
-        const float m1 = (float)(sums[c] / count), m2 = (float)(sums[C + c] / count);
-        const float w = weight ? weight[c] : 1.f;
-        o[e] = (w * is) * (g[e] - m1 - xh * m2);
+        const double is = (double)invstd[c];
+        const double xh = ((double)xv[e] - (double)mean[c]) * is;
+        const double m1 = sums[c] / count, m2 = sums[C + c] / count;
+        const double w = weight ? (double)weight[c] : 1.0;
+        o[e] = (float)((w * is) * ((double)g[e] - m1 - xh * m2));
       }
       *(f32x4*)(dx + p * lddx + 4 * cq) = o;
     }

@@ -174,7 +174,7 @@ def reduce_metric_sums(sums, group=None):
 def reduce_mean(value, group=None):
     """Average a scalar tensor over ranks (per-rank mean losses over equal local batches)."""
     if not is_dist():
-        return value
+        return value.detach()
     v = value.detach().clone().double()
     dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
     return v / dist.get_world_size(group)

@@ -27,9 +27,13 @@ def pad4(c):
 
 # ----------------------------------------------------------------------------- layout helpers
 def new_nhwc(n, c, h, w, device, ld=None, zero=False):
+    """Fresh [n, c, h, w] tensor over an [n, h, w, ld] buffer.  Built with set_() on the buffer's
+    storage so the result is a base tensor, not an autograd view (callers may modify it in place,
+    e.g. train_seg_gan.py:190), while the storage still covers the trailing pad lanes."""
     ld = pad4(c) if ld is None else ld
-    buf = (torch.zeros if zero else torch.empty)((n, h, w, ld), device=device, dtype=torch.float32)
-    return buf.permute(0, 3, 1, 2)[:, :c]
+    buf = (torch.zeros if zero else torch.empty)(n * h * w * ld, device=device, dtype=torch.float32)
+    return torch.empty(0, device=device, dtype=torch.float32).set_(
+        buf.untyped_storage(), 0, (n, c, h, w), (h * w * ld, 1, w * ld, ld))
 
 
 def nhwc_ld(x):
@@ -103,15 +107,12 @@ def _ws(nbytes, device):
 
 # ----------------------------------------------------------------------------- weight packing cache
 _WEIGHT_EPOCH = [0]
-_PACK_CACHE = {}
 
 
 def bump_weight_epoch():
     """Called by the fused optimizer (which writes parameters through raw pointers, invisible
     to tensor version counters) to invalidate packed-weight caches."""
     _WEIGHT_EPOCH[0] += 1
-    if len(_PACK_CACHE) > 4096:
-        _PACK_CACHE.clear()
 
 
 def _taps_fwd(kh, kw, pad):
@@ -125,15 +126,26 @@ def _pack(weight, transpose, taps, cred_pad, c1_for_mode):
     kmode = 0 if (cred_pad % 16 == 0 and c1_for_mode % 16 == 0) else 1
     kp = nt * cred_pad if kmode == 0 else (nt * cred_pad + 15) // 16 * 16
     rows = i if transpose else o
-    key = (weight.data_ptr(), weight._version, _WEIGHT_EPOCH[0], transpose, tuple(taps), cred_pad, kmode)
-    hit = _PACK_CACHE.get(key)
+    # The cache lives ON the parameter object (never keyed by address alone: a freed tensor's
+    # address can be reused by another weight).  Entries are valid for one (storage address,
+    # autograd version, optimizer epoch) of that parameter.
+    stamp = (weight.data_ptr(), weight._version, _WEIGHT_EPOCH[0])
+    cache = weight.__dict__.get('_ssg_pack')
+    if cache is None or cache[0] != stamp:
+        cache = (stamp, {})
+        try:
+            weight._ssg_pack = cache
+        except Exception:                        # exotic tensor subclasses: just do not cache
+            pass
+    key = (transpose, tuple(taps), cred_pad, kmode)
+    hit = cache[1].get(key)
     if hit is not None:
         return hit, kp, kmode
     out = torch.empty((rows, kp), device=weight.device, dtype=torch.float32)
     ky = (C.c_int * nt)(*[t[0] for t in taps])
     kx = (C.c_int * nt)(*[t[1] for t in taps])
     call('ssg_pack_weights_f32', ptr(weight), o, i, kh, kw, int(transpose), nt, ky, kx, kmode, cred_pad, kp, ptr(out), stream_ptr())
-    _PACK_CACHE[key] = out
+    cache[1][key] = out
     return out, kp, kmode
 
 
@@ -318,7 +330,7 @@ class _Linear(torch.autograd.Function):
         xi = x.as_strided((1, k, 1, n), (n * x.stride(0), 1, n * x.stride(0), x.stride(0)))
         y = _conv_fwd_impl(xi, None, weight.view(o, k, 1, 1), bias, 1, 0, act, slope)      # [1, o, 1, n]
         ld = _ld(y)
-        y2 = y.as_strided((n, o), (ld, 1))
+        y2 = torch.empty(0, device=y.device, dtype=torch.float32).set_(y.untyped_storage(), y.storage_offset(), (n, o), (ld, 1))
         ctx.save_for_backward(xi, weight, y if act != ACT_NONE else None)
         ctx.cfg = (act, slope, n, k, o, bias is not None)
         return y2

@@ -1,0 +1,100 @@
+"""Block-level parity against golden vectors generated from the REFERENCE's own modules
+(tests/golden/blocks.npz, made by oracle/gen_golden.py).  Weights are regenerated from the
+recorded seeds, which also proves the constructors create parameters in the reference's order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(os.path.join(GOLDEN, 'blocks.npz'))
+
+
+def _digest(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().sqrt().item()])
+
+
+def _check(mod, gold, tag, dev, fwd=None, atol=2e-5, rtol=2e-5):
+    x = torch.from_numpy(gold[tag + '_x']).to(dev).requires_grad_(True)
+    y = (fwd or mod)(x)
+    yg = gold[tag + '_y']
+    assert tuple(y.shape) == yg.shape
+    err = np.abs(y.detach().cpu().numpy() - yg).max()
+    assert err <= atol + rtol * np.abs(yg).max(), '%s fwd err %.3e' % (tag, err)
+    y.backward(torch.from_numpy(gold[tag + '_dy']).to(dev))
+    dxg = gold[tag + '_dx']
+    err = np.abs(x.grad.cpu().numpy() - dxg).max()
+    assert err <= atol + 1e-4 * np.abs(dxg).max(), '%s dx err %.3e (max %.3e)' % (tag, err, np.abs(dxg).max())
+    gd = np.stack([_digest(p.grad) for p in mod.parameters()])
+    ref = gold[tag + '_gd']
+    l2err = np.abs(gd[:, 2] - ref[:, 2])
+    assert (l2err <= 1e-4 * ref[:, 2] + 1e-5).all(), '%s grad digests: %s' % (tag, l2err.max())
+    sumerr = np.abs(gd[:, 0] - ref[:, 0])
+    assert (sumerr <= 2e-4 * ref[:, 1] + 2e-4).all(), '%s grad sums: %s' % (tag, sumerr.max())
+
+
+@pytest.mark.parametrize('tag', ['bb_a', 'bb_b', 'bb_c'])
+def test_basic_block(pkg, dev, gold, tag):
+    cin, cout, hw = [int(v) for v in gold[tag + '_cfg']]
+    torch.manual_seed(11)
+    m = pkg.archs.BasicBlock(cin, cout).to(dev).train()
+    _check(m, gold, tag, dev)
+    bufs = np.stack([_digest(b.float()) for b in m.buffers()])
+    assert np.allclose(bufs, gold[tag + '_bufs'], rtol=1e-4, atol=1e-5)
+
+
+def test_basic_block_concat_equals_cat(pkg, dev, gold):
+    """Two-pointer input == torch.cat input (archs.py:651-667)."""
+    torch.manual_seed(11)
+    m = pkg.archs.BasicBlock(48, 32).to(dev).train()
+    x = torch.from_numpy(gold['bb_b_x']).to(dev)
+    xa = x[:, :32].contiguous().requires_grad_(True); xb = x[:, 32:].contiguous().requires_grad_(True)
+    y = m(xa, xb)
+    assert np.abs(y.detach().cpu().numpy() - gold['bb_b_y']).max() < 5e-5
+    y.backward(torch.from_numpy(gold['bb_b_dy']).to(dev))
+    dx = torch.cat([xa.grad, xb.grad], 1).cpu().numpy()
+    assert np.abs(dx - gold['bb_b_dx']).max() < 5e-5
+
+
+@pytest.mark.parametrize('tag', ['sp_a', 'sp_b'])
+def test_spade(pkg, dev, gold, tag):
+    c, hw = [int(v) for v in gold[tag + '_cfg']]
+    torch.manual_seed(12)
+    m = pkg.normalization.SPADE('spadebatch3x3', c, 3, c / 16).to(dev).train()
+    _check(m, gold, tag, dev, fwd=lambda x: m(x, x))
+
+
+@pytest.mark.parametrize('tag', ['cb_a', 'cb_b', 'cb_c'])
+def test_convolutional_block(pkg, dev, gold, tag):
+    cin, cout, s, bn, hw = [int(v) for v in gold[tag + '_cfg']]
+    torch.manual_seed(13)
+    m = pkg.models_seg_gan.ConvolutionalBlock(cin, cout, 3, s, bool(bn), 'LeakyReLu').to(dev).train()
+    _check(m, gold, tag, dev)
+
+
+@pytest.mark.parametrize('tag', ['d_96', 'd_64'])
+def test_discriminator_small(pkg, dev, gold, tag):
+    torch.manual_seed(14)
+    m = pkg.models_seg_gan.Discriminator(3, 3, 8, 8, 1024).to(dev).train()
+    _check(m, gold, tag, dev, atol=5e-5, rtol=1e-4)
+
+
+def test_losses_and_metrics(pkg, dev, gold):
+    x = torch.from_numpy(gold['loss_x']).to(dev).requires_grad_(True)
+    t = torch.from_numpy(gold['loss_t']).to(dev)
+    l = pkg.losses.BCEDiceLoss()(x, t)
+    assert abs(l.item() - float(gold['loss_val'])) < 1e-5
+    l.backward()
+    assert np.abs(x.grad.cpu().numpy() - gold['loss_dx']).max() < 1e-8 + 1e-4 * np.abs(gold['loss_dx']).max()
+    assert abs(pkg.losses.StableBCELoss()(x.detach(), t).item() - float(gold['loss_bce'])) < 1e-5
+    xm, tm = x.detach()[:, 1:].clone(), t[:, 1:].clone()
+    assert abs(pkg.metrics.iou_score(xm, tm) - float(gold['loss_iou'])) < 1e-6
+    assert abs(pkg.metrics.dice_coef(xm, tm) - float(gold['loss_dice'])) < 1e-5
