@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train images/sec of the ssUnet-GAN G+D step on synthetic 3x512x512 tiles.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+One "step" = one pass of the hot path (train_seg_gan.py:182-233: G fwd+bwd, 3x D fwd+bwd, two
+clip+Adam updates) over one batch of 16 tiles per GPU already resident in HBM.  Prints ONE JSON
+line (rank 0) with the whole-job images/sec, the MFMA roofline of the dominant kernel measured
+with HIP events on the launch stream during the timed steps, and (N=1 only) a bounded CPU
+baseline: the oracle's plain-torch step timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+FLOP_PER_IMG_512 = 1.6951e12        # 2*(3*208.625 + 9*24.631) GFLOP per image per step
+PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def host_cores():
+    """Threads this process may really use: the cgroup CPU quota if there is one (a GPU box gives a
+    1-GPU job a share of its host, although affinity still lists every core), else the affinity
+    mask; capped at 32 -- beyond that a 1-image step only loses time to oversubscription."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get('SSG_CPU_BASELINE_THREADS')
+    if env:
+        return max(1, int(env))
+    return max(1, min(n, 16))          # the pool's per-GPU CPU share is 16 cores
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Oracle (plain torch CPU restatement, pinned to the reference's golden vectors) timed on a
+    bounded sample: 1 x 3 x 512 x 512 steps (the GPU workload is 16 such images per step)."""
+    from oracle import seg_gan_cpu as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    G, D, og, od = O.make_models()
+    inp, tgt = O.synthetic_batch(1, 512, 512)
+    print('[bench] cpu baseline: oracle step on %d host threads ...' % cores, file=sys.stderr, flush=True)
+    t0 = time.time()
+    O.gan_step(G, D, og, od, inp, tgt)                      # warm-up (also sizes the sample)
+    warm = time.time() - t0
+    print('[bench] cpu baseline warm-up step: %.1f s' % warm, file=sys.stderr, flush=True)
+    if warm > seconds_budget / 2:                           # slow host: the warm-up step IS the sample
+        return {'value': round(1.0 / warm, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+                'sample': '1 G+D step (first call, no warm-up) on 1x3x512x512, fp32, torch %d threads' % cores}
+    n = max(1, min(3, int((seconds_budget - warm) / max(warm, 1e-3))))
+    t0 = time.time()
+    for _ in range(n):
+        O.gan_step(G, D, og, od, inp, tgt)
+    dt = (time.time() - t0) / n
+    return {'value': round(1.0 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed G+D steps (after 1 warm-up) on 1x3x512x512, fp32, torch %d threads' % (n, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=16, help='tiles per GPU')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import ssunet_gan_amd as S
+    rank, world, local = S.dp.init_from_env()
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    torch.manual_seed(41)                                          # train_seg_gan.py:35-36
+    G = S.models_seg_gan.Generator(dict(arch='UNet_R_SS_v2', num_classes=3, input_channels=3, deep_supervision=False))
+    D = S.models_seg_gan.Discriminator(3, kernel_size=3, n_channels=64, n_blocks=8, fc_size=1024)
+    G.to(dev).train(); D.to(dev).train()
+    if world > 1:
+        S.dp.broadcast_parameters(G); S.dp.broadcast_parameters(D)
+        S.dp.convert_sync_batchnorm(G); S.dp.convert_sync_batchnorm(D)
+    og = torch.optim.Adam(params=filter(lambda p: p.requires_grad, G.parameters()), lr=2e-5)
+    od = torch.optim.Adam(params=filter(lambda p: p.requires_grad, D.parameters()), lr=2e-5)
+    crit, adv, con = S.losses.BCEDiceLoss(), nn.BCEWithLogitsLoss(), nn.MSELoss()
+    sync_g, sync_d = S.dp.grad_syncs(G, D)
+
+    gen = torch.Generator().manual_seed(7 + rank)
+    inp = torch.randn(args.batch, 3, args.size, args.size, generator=gen).to(dev)
+    tgt = (torch.rand(args.batch, 3, args.size, args.size, generator=gen) > 0.5).float().to(dev)
+
+    def step():
+        return S.train_seg_gan.gan_step(inp, tgt, G, D, crit, adv, con, og, od, 3, sync_g, sync_d)
+
+    def note(msg):
+        if rank == 0:
+            print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+    note('models on device, starting %d warm-up steps' % args.warmup)
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        note('warm-up %d: %.1f ms' % (i, (time.perf_counter() - t_w) * 1e3))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    S.ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, S.ops.PROFILE = S.ops.PROFILE, None
+    note('timed %d steps: %.1f ms/step' % (args.steps, dt / args.steps * 1e3))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / dt
+        # dominant MFMA kernel: aggregate HIP-event durations per kernel symbol
+        agg = {}
+        for label, flops, e0, e1 in prof:
+            a = agg.setdefault(label, [0.0, 0.0, 0])
+            a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+        dom = max(agg.items(), key=lambda kv: kv[1][1]) if agg else None
+        conv_t = sum(v[1] for v in agg.values()); conv_f = sum(v[0] for v in agg.values())
+        roof = None
+        if dom:
+            label, (fl, tt, cnt) = dom
+            ach = fl / tt / 1e12
+            roof = {'bound': 'mfma', 'kernel': label, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'launches': cnt, 'avg_launch_ms': round(tt / cnt * 1e3, 4),
+                    'all_mfma_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'time_frac_of_step': round(v[1] / dt, 4),
+                                             'launches': v[2]} for k, v in sorted(agg.items())},
+                    'mfma_time_frac_of_step': round(conv_t / dt, 4),
+                    'step_frac_of_conv_roofline': round(value * FLOP_PER_IMG_512 * (args.size / 512.0) ** 2 / 1e12 / PEAK_FP32_MFMA_TFLOPS / world, 4)}
+        line = {
+            'metric': 'train images/sec (512^2 tiles)', 'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'UNet_R_SS_v2 generator + SRGAN-style discriminator, one G+D step (train_seg_gan.py:182-233), '
+                                   '%d x 3x%dx%d tiles per GPU, fp32, Adam lr 2e-5' % (args.batch, args.size, args.size),
+                       'global_batch': args.batch * world, 'tile': args.size,
+                       'parallelism': 'dp%d%s' % (world, ' (RCCL grad all-reduce + sync-BN)' if world > 1 else '')},
+            'loss': round(float(out[0]), 6), 'iou': round(float(out[1]), 6), 'dice': round(float(out[2]), 6),
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

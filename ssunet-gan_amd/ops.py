@@ -156,6 +156,36 @@ def _fill_taps(desc, taps):
         desc.dx[t] = dx
 
 
+# Optional per-launch timing (bench.py): a list that receives (kernel label, algorithmic FLOPs,
+# start event, end event) for every MFMA conv launch, recorded on the launch stream.
+PROFILE = None
+
+
+def _igemm_label(cout):
+    return 'conv_igemm<128,128>' if cout > 64 else ('conv_igemm<256,64>' if cout > 32 else 'conv_igemm<256,32>')
+
+
+def _wgrad_label(cout):
+    return 'wgrad<128,128>' if cout > 64 else ('wgrad<128,64>' if cout > 32 else 'wgrad<128,32>')
+
+
+class _Timed(object):
+    def __init__(self, label, flops):
+        self.rec = PROFILE is not None
+        if self.rec:
+            self.label, self.flops = label, flops
+            self.e0 = torch.cuda.Event(enable_timing=True); self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.rec:
+            self.e0.record(torch.cuda.current_stream())
+
+    def __exit__(self, *a):
+        if self.rec:
+            self.e1.record(torch.cuda.current_stream())
+            PROFILE.append((self.label, self.flops, self.e0, self.e1))
+
+
 def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps, n, h, w, gh, gw, oh, ow,
                  in_s, out_s, out_oy, out_ox, out, bnpart=None):
     d = ConvDesc()
@@ -179,7 +209,9 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     _fill_taps(d, taps)
     d.act = act; d.slope = slope
     d.bnpart = bnpart.data_ptr() if bnpart is not None else None
-    call('ssg_conv2d_igemm_f32', C.byref(d), stream_ptr())
+    cred = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    with _Timed(_igemm_label(cout), 2.0 * n * gh * gw * cout * cred * len(taps)):
+        call('ssg_conv2d_igemm_f32', C.byref(d), stream_ptr())
 
 
 def _out_size(h, k, s, p):
@@ -260,7 +292,8 @@ def _conv_wgrad_impl(x1, x2, dy, weight_shape, stride, pad):
     nbytes = call('ssg_conv2d_wgrad_workspace_bytes', C.byref(d))
     ws = _ws(nbytes, dy.device)
     d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 8
-    call('ssg_conv2d_wgrad_f32', C.byref(d), stream_ptr())
+    with _Timed(_wgrad_label(o), 2.0 * n * oh * ow * o * i * kh * kw):
+        call('ssg_conv2d_wgrad_f32', C.byref(d), stream_ptr())
     return dw
 
 

@@ -1,0 +1,76 @@
+"""CPU: the C-ABI library loads, exports every symbol include/ssunet_hip.h declares, and the
+ctypes table in ssunet-gan_amd/_lib.py matches the header's parameter counts.  No compute calls."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, 'include', 'ssunet_hip.h')
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r'\b(?:int|int64_t|const char\*)\s+(ssg_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ('', 'void') else len([a for a in args.split(',')])
+        decls[m.group(1)] = n
+    return decls
+
+
+def test_header_has_no_torch_types_and_is_extern_c():
+    src = open(HEADER).read()
+    assert 'extern "C"' in src
+    for bad in ('torch', 'at::', 'Tensor', 'std::', 'hipStream_t'):
+        assert bad not in re.sub(r'/\*.*?\*/', '', src, flags=re.S), bad
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    decls = _declared()
+    assert len(decls) >= 35
+    lib = ctypes.CDLL(pkg._lib.LIB_PATH)
+    for name in decls:
+        assert hasattr(lib, name), 'libssunet_hip.so does not export %s' % name
+
+
+def test_ctypes_table_matches_header(pkg):
+    decls = _declared()
+    sig = pkg._lib.SIGNATURES
+    missing = set(decls) - set(sig) - {'ssg_last_error'}
+    extra = set(sig) - set(decls)
+    assert not missing and not extra, (missing, extra)
+    for name, n in decls.items():
+        if name in sig:
+            assert len(sig[name]) == n, '%s: header has %d params, ctypes table %d' % (name, n, len(sig[name]))
+    lib = pkg._lib.load()
+    assert lib.ssg_abi_version() == 1
+    assert lib.ssg_last_error() is not None
+
+
+def test_struct_layouts_match_header(pkg):
+    """Field order/count of the two descriptor structs (sizes checked against the C compiler's
+    layout rules via ctypes)."""
+    src = open(HEADER).read()
+    conv = src[src.index('typedef struct {', src.index('kmode 1')):src.index('} ssg_conv_desc;')]
+    names = re.findall(r'(\w+)(?:\[SSG_MAX_TAPS\])?\s*[;,]', re.sub(r'/\*.*?\*/', '', conv, flags=re.S))
+    got = [f[0] for f in pkg._lib.ConvDesc._fields_]
+    assert names == got, (names, got)
+    wg = src[src.index('typedef struct {', src.index('} ssg_conv_desc;')):src.index('} ssg_wgrad_desc;')]
+    names = re.findall(r'(\w+)(?:\[SSG_MAX_TAPS\])?\s*[;,]', re.sub(r'/\*.*?\*/', '', wg, flags=re.S))
+    got = [f[0] for f in pkg._lib.WgradDesc._fields_]
+    assert names == got, (names, got)
+
+
+def test_bad_arguments_return_status_not_crash(pkg):
+    """Validation happens on the host before any launch, so this is safe without a GPU."""
+    lib = pkg._lib
+    d = lib.ConvDesc()
+    rc = lib.load().ssg_conv2d_igemm_f32(ctypes.byref(d), None)
+    assert rc != 0 and b'conv' in lib.load().ssg_last_error()
+    try:
+        lib.call('ssg_conv2d_igemm_f32', ctypes.byref(d), None)
+        assert False
+    except RuntimeError as e:
+        assert 'ssg_conv2d_igemm_f32 failed' in str(e)
