@@ -1,0 +1,21 @@
+import torch, torch.nn as nn, sys
+import ssunet_gan_amd as S
+dev = torch.device('cuda')
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+torch.manual_seed(41)
+G = S.models_seg_gan.Generator(dict(arch='UNet_R_SS_v2', num_classes=3, input_channels=3, deep_supervision=False)).to(dev).train()
+D = S.models_seg_gan.Discriminator(3,3,64,8,1024).to(dev).train()
+og = torch.optim.Adam(G.parameters(), lr=2e-5); od = torch.optim.Adam(D.parameters(), lr=2e-5)
+g = torch.Generator().manual_seed(7)
+inp = torch.randn(B,3,512,512, generator=g).to(dev); tgt = (torch.rand(B,3,512,512, generator=g) > 0.5).float().to(dev)
+args = (inp, tgt, G, D, S.losses.BCEDiceLoss(), nn.BCEWithLogitsLoss(), nn.MSELoss(), og, od, 3)
+S.train_seg_gan.gan_step(*args); torch.cuda.synchronize()
+S.ops.PROFILE = []; S.ops.PROFILE_SHAPES = True
+S.train_seg_gan.gan_step(*args); torch.cuda.synchronize()
+agg = {}
+for label, fl, e0, e1 in S.ops.PROFILE:
+    a = agg.setdefault(label, [0, 0, 0]); a[0] += fl; a[1] += e0.elapsed_time(e1); a[2] += 1
+tot = sum(a[1] for a in agg.values())
+print('total mfma ms %.1f' % tot)
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+    print('%-72s x%-3d %7.2f ms %5.1f%%  %6.1f TF' % (k, a[2], a[1], 100*a[1]/tot, a[0]/a[1]/1e9))

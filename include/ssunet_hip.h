@@ -77,6 +77,14 @@ typedef struct {
 } ssg_conv_desc;
 
 int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream);
+/* Dispatching entry point (what the host side calls): convs with <= 8 channels on one side and
+ * unit strides (SPADE's C->3->h->C chain normalization.py:90-96, the 3-channel image / logit /
+ * mask layers archs.py:210,615, models_seg_gan.py:37) run on HBM-bound VALU kernels; everything
+ * else goes to the MFMA implicit GEMM above.  Same descriptor, same semantics.
+ * ssg_conv2d_kernel_id: 0..2 = conv_igemm<128,128>/<256,64>/<256,32>, 10 = thin small-Cout,
+ * 11 = thin small-Cin (profiling labels). */
+int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream);
+int ssg_conv2d_kernel_id(const ssg_conv_desc* d);
 /* number of M-tiles the launch above uses (rows of bnpart) */
 int ssg_conv2d_igemm_mtiles(const ssg_conv_desc* d);
 
@@ -108,6 +116,8 @@ typedef struct {
 
 int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d);
 int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream);
+/* 0..2 = wgrad<128,128>/<128,64>/<128,32> (MFMA), 13 = thin (dout <= 4 ch), 14 = thin (in = 4 ch) */
+int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d);
 
 /* ------------------------------------------------------------------ layout helpers
  * NCHW (the reference's layout at the boundary: dataset.py:144 tensors, G logits) <->
@@ -215,6 +225,12 @@ int ssg_clamp_f32(float* x, int64_t n, float lo, float hi, void* stream);
 
 /* per-channel sums over pixels: out[c] = sum_p x[p,c] (bias gradients) */
 int ssg_channel_sum_f32(const float* x, int64_t P, int C, int ld, float* out, void* ws, void* stream);
+
+/* ------------------------------------------------------------------ calibration (bench only)
+ * Measured ceilings of the device the job runs on: back-to-back fp32 32x32x2 MFMA issue
+ * (FLOPs = blocks*4*iters*16*4096; scratch holds blocks*256 floats) and a 16-B/lane HBM copy. */
+int ssg_tool_mfma_peak_f32(float* scratch, int blocks, int iters, void* stream);
+int ssg_tool_copy_f32(const float* src, float* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,9 @@ SIGNATURES = {
     'ssg_abi_version': [],
     'ssg_conv2d_igemm_f32': [C.POINTER(ConvDesc), _P],
     'ssg_conv2d_igemm_mtiles': [C.POINTER(ConvDesc)],
+    'ssg_conv2d_f32': [C.POINTER(ConvDesc), _P],
+    'ssg_conv2d_kernel_id': [C.POINTER(ConvDesc)],
+    'ssg_conv2d_wgrad_kernel_id': [C.POINTER(WgradDesc)],
     'ssg_pack_weights_f32': [_P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _P, _P],
     'ssg_conv2d_wgrad_workspace_bytes': [C.POINTER(WgradDesc)],
     'ssg_conv2d_wgrad_f32': [C.POINTER(WgradDesc), _P],
@@ -94,13 +97,15 @@ SIGNATURES = {
     'ssg_clamp_adam_multi_f32': [_P, _P, _P, _P, _I, _F, _D, _D, _D, _D, _D, _D, _D, _P],
     'ssg_clamp_f32': [_P, _L, _F, _F, _P],
     'ssg_channel_sum_f32': [_P, _L, _I, _I, _P, _P, _P],
+    'ssg_tool_mfma_peak_f32': [_P, _I, _I, _P],
+    'ssg_tool_copy_f32': [_P, _P, _L, _P],
 }
 _RESTYPES = {
     'ssg_conv2d_wgrad_workspace_bytes': C.c_int64,
     'ssg_bn_workspace_bytes': C.c_int64,
     'ssg_seg_loss_workspace_bytes': C.c_int64,
 }
-_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_igemm_mtiles'}
+_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_igemm_mtiles', 'ssg_conv2d_kernel_id', 'ssg_conv2d_wgrad_kernel_id'}
 
 _lib = None
 

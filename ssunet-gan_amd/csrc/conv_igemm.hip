@@ -18,6 +18,11 @@
 //     of step s and written to the other LDS buffer after them; one barrier per K-step.
 //     Each K-step is MI*NI*8 MFMAs x 64 cycles per wave, long enough to cover L2/HBM latency.
 #include "common.h"
+#include "conv_thin.h"
+
+#ifndef SSG_EXPERIMENT
+#define SSG_EXPERIMENT 0
+#endif
 
 namespace {
 
@@ -150,7 +155,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   for (int s = 0; s < a.nsteps; ++s) {
     const int buf = s & 1;
     const bool more = (s + 1) < a.nsteps;
+#if SSG_EXPERIMENT != 1
     if (more) load_step(s + 1);
+#endif
     const float* Ab = As + buf * BM * LDS_ROW + (wm * WTM + l31) * LDS_ROW + 4 * half;
     const float* Bb = Bs + buf * BN * LDS_ROW + (wn * WTN + l31) * LDS_ROW + 4 * half;
 #pragma unroll
@@ -168,7 +175,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
           for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
+#if SSG_EXPERIMENT != 1 && SSG_EXPERIMENT != 2
     if (more) store_step(buf ^ 1);
+#elif SSG_EXPERIMENT == 2
+    for (int j = 0; j < A_LD; ++j) asm volatile("" :: "v"(ra[j]));
+    for (int j = 0; j < B_LD; ++j) asm volatile("" :: "v"(rb[j]));
+#endif
     __syncthreads();
   }
 
@@ -313,4 +325,22 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
     case 1: return launch<256, 64, 4, 1>(a, st);
     default: return launch<256, 32, 4, 1>(a, st);
   }
+}
+
+// Dispatcher: thin VALU kernels for the <= 8-channel cases, MFMA implicit GEMM otherwise.
+// ssg_conv2d_kernel_id reports which kernel a descriptor maps to (for profiling labels):
+//   0..2 = conv_igemm<128,128> / <256,64> / <256,32>, 10 = thin small-Cout, 11 = thin small-Cin.
+extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
+  if (!d) return SSG_EINVAL;
+  const int k = ssg_thin_conv_kind(d);
+  if (k) return 9 + k;
+  return pick_variant(d);
+}
+
+extern "C" int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream) {
+  int rc = validate(d);
+  if (rc != SSG_OK) return rc;
+  const int k = ssg_thin_conv_kind(d);
+  if (k) return ssg_thin_conv_launch(d, k, (hipStream_t)stream);
+  return ssg_conv2d_igemm_f32(d, stream);
 }

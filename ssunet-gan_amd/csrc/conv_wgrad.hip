@@ -9,6 +9,7 @@
 // an ordered second-stage kernel sums the slabs and scatters into the OIHW gradient, so the
 // result is bitwise reproducible (no float atomics).
 #include "common.h"
+#include "conv_thin.h"
 
 namespace {
 
@@ -153,16 +154,26 @@ struct RedArgs {
   int ky[SSG_MAX_TAPS], kx[SSG_MAX_TAPS];
 };
 
+// 32 gradient elements x 8 split-lanes per block: lane z adds slabs z, z+8, ... in order, then the
+// 8 lane sums are added in lane order -> fixed summation order, short serial chains.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const long long idx = (long long)blockIdx.x * 32 + el;
   const long long tot = (long long)a.M * a.Cout;
-  if (idx >= tot) return;
+  float s = 0.f;
+  if (idx < tot)
+    for (int z = zl; z < a.splits; z += 8) s += a.ws[(size_t)z * tot + idx];
+  red[zl][el] = s;
+  __syncthreads();
+  if (zl != 0 || idx >= tot) return;
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v += red[k][el];
   const int row = (int)(idx / a.Cout), co = (int)(idx - (long long)row * a.Cout);
   const int t = row / a.Cin, c = row - t * a.Cin;
   if (c >= a.Cin_real) return;
-  float s = 0.f;
-  for (int z = 0; z < a.splits; ++z) s += a.ws[(size_t)z * tot + idx];
-  a.dw[(((size_t)co * a.Cin_real + c) * a.KH + a.ky[t]) * a.KW + a.kx[t]] = s;
+  a.dw[(((size_t)co * a.Cin_real + c) * a.KH + a.ky[t]) * a.KW + a.kx[t]] = v;
 }
 
 struct Plan { int variant, mt, nt, splits, steps_per_split; };
@@ -235,6 +246,10 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 
 extern "C" int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d) {
   if (!d) return 0;
+  if (ssg_thin_wgrad_kind(d)) {
+    const int splits = ssg_thin_wgrad_splits(d, nullptr);
+    return (int64_t)splits * d->ntaps * (d->C1 + d->C2) * d->Cout * (int64_t)sizeof(float);
+  }
   const Plan p = make_plan(d);
   return (int64_t)p.splits * d->ntaps * (d->C1 + d->C2) * d->Cout * (int64_t)sizeof(float);
 }
@@ -242,8 +257,9 @@ extern "C" int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d) {
 extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   int rc = validate(d);
   if (rc != SSG_OK) return rc;
-  const Plan p = make_plan(d);
+  Plan p = make_plan(d);
   hipStream_t st = (hipStream_t)stream;
+  const int thin = ssg_thin_wgrad_kind(d);
   WgArgs a;
   a.in1 = d->in1; a.in2 = d->C2 ? d->in2 : d->in1; a.dout = d->dout; a.ws = d->ws;
   a.C1 = d->C1; a.C2 = d->C2; a.ld1 = d->ld1; a.ld2 = d->C2 ? d->ld2 : d->ld1;
@@ -255,19 +271,25 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   a.M = d->ntaps * (d->C1 + d->C2);
   a.Ptot = (long long)d->N * d->GH * d->GW;
   a.steps_per_split = p.steps_per_split;
-  dim3 grid((unsigned)p.mt, (unsigned)p.nt, (unsigned)p.splits);
-  switch (p.variant) {
-    case 0: hipLaunchKernelGGL((wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, a); break;
+  if (thin) {
+    p.splits = ssg_thin_wgrad_splits(d, nullptr);
+    rc = ssg_thin_wgrad_launch(d, thin, st);
+    if (rc != SSG_OK) return rc;
+  } else {
+    dim3 grid((unsigned)p.mt, (unsigned)p.nt, (unsigned)p.splits);
+    switch (p.variant) {
+      case 0: hipLaunchKernelGGL((wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a); break;
+      case 1: hipLaunchKernelGGL((wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, a); break;
+    }
+    SSG_LAUNCH_CHECK();
   }
-  SSG_LAUNCH_CHECK();
   RedArgs r;
   r.ws = d->ws; r.dw = d->dw_oihw; r.splits = p.splits; r.M = a.M; r.Cout = d->Cout; r.Cin = d->C1 + d->C2;
   r.Cin_real = d->Cin_real; r.KH = d->KH; r.KW = d->KW; r.ntaps = d->ntaps;
   for (int t = 0; t < SSG_MAX_TAPS; ++t) { r.ky[t] = t < d->ntaps ? d->ky[t] : 0; r.kx[t] = t < d->ntaps ? d->kx[t] : 0; }
   const long long tot = (long long)a.M * d->Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ssg_cdiv(tot, 256)), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ssg_cdiv(tot, 32)), dim3(256), 0, st, r);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -293,4 +315,12 @@ extern "C" int ssg_pack_weights_f32(const float* w_oihw, int O, int I, int KH, i
                      w_oihw, O, I, KH, KW, transpose, ntaps, bits, kmode, Cred_pad, Kp, R, out);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
+}
+
+// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 13/14 = thin
+extern "C" int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d) {
+  if (!d) return SSG_EINVAL;
+  const int k = ssg_thin_wgrad_kind(d);
+  if (k) return 10 + k;
+  return make_plan(d).variant;
 }

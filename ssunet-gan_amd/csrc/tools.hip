@@ -1,0 +1,49 @@
+// Calibration kernels (not on the hot path): measured fp32-MFMA issue peak and HBM copy rate of
+// THIS device, so roofline fractions can be read against what the box sustains as well as the spec.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f + blockIdx.x * 1e-6f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    a += 1e-7f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long long nq) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+}  // namespace
+
+// Launches `blocks` workgroups of 4 waves, each wave issuing iters*16 independent-accumulator
+// 32x32x2 fp32 MFMAs (4096 FLOP each).  FLOPs = blocks * 4 * iters * 16 * 4096.
+extern "C" int ssg_tool_mfma_peak_f32(float* scratch, int blocks, int iters, void* stream) {
+  SSG_REQUIRE(scratch && blocks > 0 && iters > 0, SSG_EINVAL, "mfma_peak: bad args");
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+extern "C" int ssg_tool_copy_f32(const float* src, float* dst, int64_t n, void* stream) {
+  SSG_REQUIRE(src && dst && n > 0 && n % 4 == 0, SSG_EINVAL, "copy: bad args");
+  hipLaunchKernelGGL(copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, (long long)(n / 4));
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}

@@ -159,14 +159,12 @@ def _fill_taps(desc, taps):
 # Optional per-launch timing (bench.py): a list that receives (kernel label, algorithmic FLOPs,
 # start event, end event) for every MFMA conv launch, recorded on the launch stream.
 PROFILE = None
+PROFILE_SHAPES = False      # debug: append the launch geometry to the label
 
 
-def _igemm_label(cout):
-    return 'conv_igemm<128,128>' if cout > 64 else ('conv_igemm<256,64>' if cout > 32 else 'conv_igemm<256,32>')
-
-
-def _wgrad_label(cout):
-    return 'wgrad<128,128>' if cout > 64 else ('wgrad<128,64>' if cout > 32 else 'wgrad<128,32>')
+_CONV_LABELS = {0: 'conv_igemm<128,128>', 1: 'conv_igemm<256,64>', 2: 'conv_igemm<256,32>',
+                10: 'thin_small_cout', 11: 'thin_small_cin'}
+_WGRAD_LABELS = {0: 'wgrad<128,128>', 1: 'wgrad<128,64>', 2: 'wgrad<128,32>', 13: 'thin_wgrad_small_cout', 14: 'thin_wgrad_small_cin'}
 
 
 class _Timed(object):
@@ -210,8 +208,13 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     d.act = act; d.slope = slope
     d.bnpart = bnpart.data_ptr() if bnpart is not None else None
     cred = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
-    with _Timed(_igemm_label(cout), 2.0 * n * gh * gw * cout * cred * len(taps)):
-        call('ssg_conv2d_igemm_f32', C.byref(d), stream_ptr())
+    label = None
+    if PROFILE is not None:
+        label = _CONV_LABELS.get(call('ssg_conv2d_kernel_id', C.byref(d)), '?')
+        if PROFILE_SHAPES:
+            label += ' n%d %dx%d cin%d cout%d taps%d s%d/%d' % (n, gh, gw, cred, cout, len(taps), in_s, out_s)
+    with _Timed(label, 2.0 * n * gh * gw * cout * cred * len(taps)):
+        call('ssg_conv2d_f32', C.byref(d), stream_ptr())
 
 
 def _out_size(h, k, s, p):
@@ -292,7 +295,12 @@ def _conv_wgrad_impl(x1, x2, dy, weight_shape, stride, pad):
     nbytes = call('ssg_conv2d_wgrad_workspace_bytes', C.byref(d))
     ws = _ws(nbytes, dy.device)
     d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 8
-    with _Timed(_wgrad_label(o), 2.0 * n * oh * ow * o * i * kh * kw):
+    label = None
+    if PROFILE is not None:
+        label = _WGRAD_LABELS.get(call('ssg_conv2d_wgrad_kernel_id', C.byref(d)), '?')
+        if PROFILE_SHAPES:
+            label += ' n%d %dx%d cin%d cout%d k%d s%d' % (n, oh, ow, i, o, kh, stride)
+    with _Timed(label, 2.0 * n * oh * ow * o * i * kh * kw):
         call('ssg_conv2d_wgrad_f32', C.byref(d), stream_ptr())
     return dw
 

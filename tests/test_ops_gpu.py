@@ -257,3 +257,14 @@ def test_layout_roundtrip_and_errors(pkg, dev):
         pkg.ops.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 3, 3), None, 1, 1)      # CPU tensor: no fallback
     with pytest.raises(ValueError):
         pkg.ops.conv2d(torch.randn(1, 4, 4, 4).to(dev), torch.randn(4, 8, 3, 3).to(dev), None, 1, 1)
+
+
+def test_all_thin_kernels_enabled_subprocess():
+    """The thin VALU kernels that are off by default (SSG_THIN_MASK, conv_thin.hip) stay exact:
+    rerun the conv cases in a subprocess with all four enabled."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, SSG_THIN_MASK='15')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_ops_gpu.py'), '-m', 'gpu', '-q', '-x',
+                        '-k', 'conv2d_fwd_bwd or concat', '-p', 'no:cacheprovider'], env=env, cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
