@@ -81,8 +81,9 @@ int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream);
  * unit strides (SPADE's C->3->h->C chain normalization.py:90-96, the 3-channel image / logit /
  * mask layers archs.py:210,615, models_seg_gan.py:37) run on HBM-bound VALU kernels; everything
  * else goes to the MFMA implicit GEMM above.  Same descriptor, same semantics.
- * ssg_conv2d_kernel_id: 0..2 = conv_igemm<128,128>/<256,64>/<256,32>, 10 = thin small-Cout,
- * 11 = thin small-Cin (profiling labels). */
+ * ssg_conv2d_kernel_id: 0..2 = conv_igemm_kernel<128,128>/<256,64>/<256,32> (register-staged),
+ * 20/21 = conv_igemm_dma_kernel<128,128>/<256,64> (LDS-DMA pipeline, the default for Cin % 16 == 0
+ * and Cout > 32), 10 = thin small-Cout, 11 = thin small-Cin (profiling labels). */
 int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream);
 int ssg_conv2d_kernel_id(const ssg_conv_desc* d);
 /* number of M-tiles the launch above uses (rows of bnpart) */
@@ -116,7 +117,8 @@ typedef struct {
 
 int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d);
 int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream);
-/* 0..2 = wgrad<128,128>/<128,64>/<128,32> (MFMA), 13 = thin (dout <= 4 ch), 14 = thin (in = 4 ch) */
+/* 0..2 = wgrad_kernel<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma_kernel<128,128>/<128,64> (default
+ * for Cout > 32), 13 = thin (dout <= 4 ch), 14 = thin (in = 4 ch) */
 int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d);
 
 /* ------------------------------------------------------------------ layout helpers

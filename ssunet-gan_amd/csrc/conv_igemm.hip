@@ -19,27 +19,14 @@
 //     Each K-step is MI*NI*8 MFMAs x 64 cycles per wave, long enough to cover L2/HBM latency.
 #include "common.h"
 #include "conv_thin.h"
+#include "conv_args.h"
+#include <stdlib.h>
 
 #ifndef SSG_EXPERIMENT
 #define SSG_EXPERIMENT 0
 #endif
 
 namespace {
-
-struct ConvArgs {
-  const float* in1; const float* in2;
-  const float* w; const float* bias; const float* res; float* out; float* bnpart;
-  int C1, C2, ld1, ld2;
-  int N, H, W;
-  int Kp, kmode;
-  int ldr, Cout, ldo;
-  int GH, GW, OH, OW;
-  int in_sy, in_sx, out_sy, out_sx, out_oy, out_ox;
-  int ntaps;
-  unsigned long long tap_bits;   // 6 bits per tap: (dy+2) | (dx+2)<<3
-  int act; float slope;
-  int tiles_x, tiles_y, nsteps;
-};
 
 constexpr int LDS_ROW = 20;   // floats per LDS row (16 data + 4 pad = 80 bytes)
 
@@ -257,6 +244,13 @@ int pick_variant(const ssg_conv_desc* d) {
   return 2;                         // 256 x 32
 }
 
+// LDS-DMA pipeline (conv_igemm_dma.hip) for the dense layers; SSG_IGEMM_DMA=0 falls back to the
+// register-staged kernel (A/B switch for measurements).
+bool uses_dma(const ssg_conv_desc* d) {
+  static const int use_dma = [] { const char* e = getenv("SSG_IGEMM_DMA"); return e ? atoi(e) : 1; }();
+  return use_dma && d->kmode == 0 && d->Cout > 32 && d->bnpart == nullptr;
+}
+
 int validate(const ssg_conv_desc* d) {
   SSG_REQUIRE(d != nullptr, SSG_EINVAL, "conv: null desc");
   SSG_REQUIRE(d->in1 && d->w && d->out, SSG_EINVAL, "conv: null pointer");
@@ -320,6 +314,7 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
   if (rc != SSG_OK) return rc;
   const ConvArgs a = to_args(d);
   hipStream_t st = (hipStream_t)stream;
+  if (uses_dma(d)) return ssg_conv_igemm_dma_launch(a, pick_variant(d), st);
   switch (pick_variant(d)) {
     case 0: return launch<128, 128, 2, 2>(a, st);
     case 1: return launch<256, 64, 4, 1>(a, st);
@@ -329,12 +324,13 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
 
 // Dispatcher: thin VALU kernels for the <= 8-channel cases, MFMA implicit GEMM otherwise.
 // ssg_conv2d_kernel_id reports which kernel a descriptor maps to (for profiling labels):
-//   0..2 = conv_igemm<128,128> / <256,64> / <256,32>, 10 = thin small-Cout, 11 = thin small-Cin.
+//   0..2 = conv_igemm<128,128> / <256,64> / <256,32>, 20/21 = conv_igemm_dma<128,128> / <256,64>,
+//   10 = thin small-Cout, 11 = thin small-Cin.
 extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
   if (!d) return SSG_EINVAL;
   const int k = ssg_thin_conv_kind(d);
   if (k) return 9 + k;
-  return pick_variant(d);
+  return pick_variant(d) + (uses_dma(d) ? 20 : 0);
 }
 
 extern "C" int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream) {

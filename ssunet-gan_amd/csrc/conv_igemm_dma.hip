@@ -1,0 +1,193 @@
+// Implicit-GEMM convolution, LDS-DMA pipeline (gfx950).  Same contract as conv_igemm.hip's kernel
+// (ssg_conv2d_igemm_f32, kmode 0 only: Cin % 16 == 0); selected for the dense layers.
+//
+// What changes against the register-staged kernel:
+//   * A and B tiles go global -> LDS directly with `global_load_lds_dwordx4` (one 1-KiB piece =
+//     16 rows x 64 B per wave-instruction): no staging VGPRs, no ds_write pass, no vmcnt(0)
+//     before a write pass, ~6 VALU per piece instead of ~35 for the predicated register loads.
+//   * the LDS image is the DMA's lane-linear one ([row][16 floats], 64-B rows, no padding);
+//     bank conflicts of the one-row-per-lane ds_read_b128 are removed by an XOR swizzle applied
+//     on the SOURCE address (16-B position p of row r holds channel quad p ^ ((r>>2)&3)) and
+//     mirrored on the read.
+//   * out-of-image taps and rows beyond Cout read a zero page (a __device__ array), so the DMA
+//     needs no predication.
+//   * 3 LDS stages, two K-steps in flight across the single barrier per step:
+//       wait vmcnt(pieces of 1 step) ; s_barrier ; issue step s+2 ; 32 MFMAs on step s.
+//     The barrier both publishes step s (every wave has waited for its own pieces) and proves
+//     stage (s+2)%3 == (s-1)%3 is no longer read.
+#include "common.h"
+#include "conv_args.h"
+
+namespace {
+
+__device__ __attribute__((aligned(64))) float ssg_zero_page[64];
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void dma16(const float* src, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+}
+
+constexpr int NSTAGE = 3;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
+  constexpr int TH = BM / 16;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int A_PC = BM / 64;          // A pieces (16 rows each) per wave per K-step
+  constexpr int B_PC = BN / 64;          // B pieces per wave per K-step
+  constexpr int STAGE = (BM + BN) * 16;  // floats per stage
+  static_assert(B_PC >= 1, "BN >= 64");
+
+  __shared__ __attribute__((aligned(1024))) float lds[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int n = bid / a.tiles_y;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-lane DMA source state.  Piece j of this wave covers tile rows [(wave*PC + j)*16, +16);
+  // lane l writes row r = base + (l>>2), 16-B position p = l&3, i.e. channel quad q = p ^ ((r>>2)&3).
+  const int lr = lane >> 2, lp = lane & 3;
+  int a_iy0[A_PC], a_ix0[A_PC];
+  int a_q[A_PC];
+#pragma unroll
+  for (int j = 0; j < A_PC; ++j) {
+    const int r = (wave * A_PC + j) * 16 + lr;
+    const int gy = ty * TH + (r >> 4), gx = tx * 16 + (r & 15);
+    const bool ok = (gy < a.GH) && (gx < a.GW);
+    a_iy0[j] = ok ? gy * a.in_sy : -100000;
+    a_ix0[j] = gx * a.in_sx;
+    a_q[j] = 4 * (lp ^ ((r >> 2) & 3));
+  }
+  const float* b_src[B_PC];
+#pragma unroll
+  for (int j = 0; j < B_PC; ++j) {
+    const int r = (wave * B_PC + j) * 16 + lr;
+    const int q = 4 * (lp ^ ((r >> 2) & 3));
+    b_src[j] = (n0 + r < a.Cout) ? a.w + (size_t)(n0 + r) * a.Kp + q : nullptr;
+  }
+  const float* zero = ssg_zero_page;
+
+  auto issue = [&](int s) {
+    float* st = lds + (s % NSTAGE) * STAGE;
+    const int chunk = s / a.ntaps;
+    const int t = s - chunk * a.ntaps;
+    const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
+    const int dy = (tb & 7) - 2, dx = (tb >> 3) - 2;
+    const int c0 = chunk * 16;
+    const float* src; int ld, cc;
+    if (c0 < a.C1) { src = a.in1; ld = a.ld1; cc = c0; } else { src = a.in2; ld = a.ld2; cc = c0 - a.C1; }
+#pragma unroll
+    for (int j = 0; j < A_PC; ++j) {
+      const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const float* p = ok ? src + ((size_t)(n * a.H + iy) * a.W + ix) * ld + cc + a_q[j] : zero;
+      dma16(p, st + (wave * A_PC + j) * 256);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PC; ++j) {
+      const float* p = b_src[j] ? b_src[j] + (size_t)s * 16 : zero;
+      dma16(p, st + BM * 16 + (wave * B_PC + j) * 256);
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int half = lane >> 5, l31 = lane & 31;
+  const int sw = (l31 >> 2) & 3;
+  // float offsets of the four channel quads of this lane's row inside a 16-float LDS row
+  const int qoff0 = 4 * ((0 + half) ^ sw), qoff1 = 4 * ((2 + half) ^ sw);
+
+  const int nsteps = a.nsteps;
+  issue(0);
+  if (nsteps > 1) issue(1);
+
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PC + B_PC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + 2 < nsteps) issue(s + 2);
+    const float* st = lds + (s % NSTAGE) * STAGE;
+    const float* Ab = st + (wm * WTM + l31) * 16;
+    const float* Bb = st + BM * 16 + (wn * WTN + l31) * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int qo = h == 0 ? qoff0 : qoff1;
+      f32x4 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *(const f32x4*)(Ab + i * 32 * 16 + qo);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = *(const f32x4*)(Bb + j * 32 * 16 + qo);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue (identical to conv_igemm.hip): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn * WTN + j * 32 + l31;
+    const bool cok = co < a.Cout;
+    const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int gy = ty * TH + (p >> 4), gx = tx * 16 + (p & 15);
+        if (gy < a.GH && gx < a.GW) {
+          const size_t pix = ((size_t)(n * a.OH + gy * a.out_sy + a.out_oy) * a.OW + gx * a.out_sx + a.out_ox);
+          float v = acc[i][j][r] + bv;
+          if (cok) {
+            if (a.res) v += a.res[pix * a.ldr + co];
+            if (a.act == SSG_ACT_RELU) v = v < 0.f ? 0.f : v;
+            else if (a.act == SSG_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+            a.out[pix * a.ldo + co] = v;
+          } else if (co < ((a.Cout + 3) & ~3)) {
+            a.out[pix * a.ldo + co] = 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  constexpr int TH = BM / 16;
+  a.tiles_x = (a.GW + 15) / 16;
+  a.tiles_y = (a.GH + TH - 1) / TH;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)((a.Cout + BN - 1) / BN));
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), 0, st, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+}  // namespace
+
+// Called by ssg_conv2d_igemm_f32 (conv_igemm.hip) for kmode 0, Cout > 32, no bnpart.
+int ssg_conv_igemm_dma_launch(const ConvArgs& a, int variant, hipStream_t st) {
+  if (variant == 0) return launch<128, 128, 2, 2>(a, st);
+  return launch<256, 64, 4, 1>(a, st);
+}

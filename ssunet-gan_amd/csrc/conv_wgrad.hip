@@ -10,17 +10,10 @@
 // result is bitwise reproducible (no float atomics).
 #include "common.h"
 #include "conv_thin.h"
+#include "conv_wgrad_args.h"
+#include <stdlib.h>
 
 namespace {
-
-struct WgArgs {
-  const float* in1; const float* in2; const float* dout; float* ws;
-  int C1, C2, ld1, ld2, N, H, W, Cout, ldd, GH, GW, in_sy, in_sx, ntaps;
-  unsigned long long tap_bits;
-  int M;                 // ntaps * Cin
-  long long Ptot;        // N*GH*GW
-  int steps_per_split;   // K-steps (16 pixels each) per z-slice
-};
 
 constexpr int BKP = 16;
 
@@ -178,6 +171,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
 
 struct Plan { int variant, mt, nt, splits, steps_per_split; };
 
+bool wgrad_uses_dma(int variant) {
+  static const int use_dma = [] { const char* e = getenv("SSG_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+  return use_dma && variant <= 1;
+}
+
 Plan make_plan(const ssg_wgrad_desc* d) {
   Plan p;
   const int Cin = d->C1 + d->C2;
@@ -277,6 +275,10 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
     if (rc != SSG_OK) return rc;
   } else {
     dim3 grid((unsigned)p.mt, (unsigned)p.nt, (unsigned)p.splits);
+    if (wgrad_uses_dma(p.variant)) {
+      rc = ssg_wgrad_dma_launch(a, p.variant, grid, st);
+      if (rc != SSG_OK) return rc;
+    } else
     switch (p.variant) {
       case 0: hipLaunchKernelGGL((wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a); break;
       case 1: hipLaunchKernelGGL((wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, a); break;
@@ -317,10 +319,11 @@ extern "C" int ssg_pack_weights_f32(const float* w_oihw, int O, int I, int KH, i
   return SSG_OK;
 }
 
-// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 13/14 = thin
+// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 13/14 = thin
 extern "C" int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d) {
   if (!d) return SSG_EINVAL;
   const int k = ssg_thin_wgrad_kind(d);
   if (k) return 10 + k;
-  return make_plan(d).variant;
+  const int v = make_plan(d).variant;
+  return v + (wgrad_uses_dma(v) ? 20 : 0);
 }

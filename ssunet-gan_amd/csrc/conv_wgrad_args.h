@@ -1,0 +1,16 @@
+// Kernel-argument block shared by the two weight-gradient kernels (internal).
+#pragma once
+#include "common.h"
+
+struct WgArgs {
+  const float* in1; const float* in2; const float* dout; float* ws;
+  int C1, C2, ld1, ld2, N, H, W, Cout, ldd, GH, GW, in_sy, in_sx, ntaps;
+  unsigned long long tap_bits;
+  int M;                 // ntaps * Cin
+  long long Ptot;        // N*GH*GW
+  int steps_per_split;   // K-steps (16 pixels each) per z-slice
+};
+
+
+// conv_wgrad_dma.hip: LDS-DMA pipeline for Cout > 32 (variant 0 = <128,128>, 1 = <128,64>)
+int ssg_wgrad_dma_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t st);
