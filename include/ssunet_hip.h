@@ -228,6 +228,44 @@ int ssg_clamp_f32(float* x, int64_t n, float lo, float hi, void* stream);
 /* per-channel sums over pixels: out[c] = sum_p x[p,c] (bias gradients) */
 int ssg_channel_sum_f32(const float* x, int64_t P, int C, int ld, float* out, void* ws, void* stream);
 
+/* ------------------------------------------------------------------ unwired per-op kernels
+ * Depthwise convolution (groups = C): EfficientNet MBConv k in {3,5}, s in {1,2} with TF "same"
+ * static padding (efficientnet_pytorch/model.py:46-50, utils.py:123-146) and the 9x9 gate conv of
+ * xresidualblock.py:16.  `w` is the reference's [C][1][KH][KW] parameter tensor as is.
+ *   fwd  : out[n,oy,ox,c] = bias[c] + sum_k in[n, oy*s+ky-pad_top, ox*s+kx-pad_left, c] * w[c,ky,kx]
+ *   dgrad: gradient w.r.t. in;  wgrad: gradient w.r.t. w (fp64 two-stage reduction, deterministic) */
+int ssg_dwconv2d_fwd_f32(const float* in, int N, int H, int W, int C, int ld, const float* w, const float* bias, int KH, int KW,
+                         int stride, int pad_top, int pad_left, int OH, int OW, float* out, int ldo, void* stream);
+int ssg_dwconv2d_dgrad_f32(const float* dout, int lddo, int N, int H, int W, int C, const float* w, int KH, int KW, int stride,
+                           int pad_top, int pad_left, int OH, int OW, float* dx, int lddx, void* stream);
+int64_t ssg_dwconv2d_wgrad_workspace_bytes(int N, int OH, int OW, int C, int KH, int KW);
+int ssg_dwconv2d_wgrad_f32(const float* in, int N, int H, int W, int C, int ld, const float* dout, int lddo, int KH, int KW,
+                           int stride, int pad_top, int pad_left, int OH, int OW, float* dw, void* ws, void* stream);
+/* element-wise: swish x*sigmoid(x) with the reference's backward (efficientnet_pytorch/utils.py:37-48),
+ * sigmoid (SE gate, model.py:79), Gaussian exp(-x^2) (xresidualblock.py:5-7) */
+#define SSG_UNARY_SWISH 0
+#define SSG_UNARY_SIGMOID 1
+#define SSG_UNARY_GAUSSIAN 2
+int ssg_unary_fwd_f32(const float* x, int ldx, int64_t P, int C, int op, float* y, int ldy, void* stream);
+int ssg_unary_bwd_f32(const float* x, int ldx, const float* dy, int lddy, int64_t P, int C, int op, float* dx, int lddx, void* stream);
+/* y = a*b (xresidualblock.py:23) and its gradients */
+int ssg_mul_fwd_f32(const float* a, int lda, const float* b, int ldb, int64_t P, int C, float* y, int ldy, void* stream);
+int ssg_mul_bwd_f32(const float* a, int lda, const float* b, int ldb, const float* dy, int lddy, int64_t P, int C,
+                    float* da, int ldda, float* db, int lddb, void* stream);
+/* squeeze-excite plumbing (model.py:76-80): y[n,p,c] = x[n,p,c]*s[n,c]; out[n,c] = scale*sum_p a[n,p,c]*(b?b[n,p,c]:1)
+ * (global average pool and the gate's gradient); y[n,p,c] = scale*s[n,c] (average-pool backward) */
+int ssg_channel_scale_fwd_f32(const float* x, int ldx, const float* s, int N, int64_t S, int C, float* y, int ldy, void* stream);
+int ssg_sample_channel_sum_f32(const float* a, int lda, const float* b, int ldb, int N, int64_t S, int C, float scale, float* out, void* stream);
+int ssg_broadcast_rows_f32(const float* s, int N, int64_t S, int C, float scale, float* y, int ldy, void* stream);
+/* Spectral norm (spectral_norm.py:38-88): power iteration on W [rows][cols] with in-place u [rows],
+ * v [cols]; W_out = W / sigma, sigma = u.(W v).  Backward treats u, v as constants:
+ * dW = dWsn/sigma - (sum(dWsn.W)/sigma^2) u v^T. */
+int64_t ssg_spectral_norm_workspace_bytes(int rows, int cols);
+int ssg_spectral_norm_fwd_f32(const float* W, int rows, int cols, float* u, float* v, int n_power_iterations, double eps,
+                              float* W_out, float* sigma, void* ws, void* stream);
+int ssg_spectral_norm_bwd_f32(const float* dWsn, const float* W, int rows, int cols, const float* u, const float* v,
+                              const float* sigma, float* dW, void* ws, void* stream);
+
 /* ------------------------------------------------------------------ calibration (bench only)
  * Measured ceilings of the device the job runs on: back-to-back fp32 32x32x2 MFMA issue
  * (FLOPs = blocks*4*iters*16*4096; scratch holds blocks*256 floats) and a 16-B/lane HBM copy. */

@@ -205,6 +205,92 @@ def gen_blocks(mods):
     print('blocks.npz written,', len(data), 'arrays')
 
 
+def gen_unwired(mods):
+    """Golden vectors for the named-but-unwired blocks, from the
+    reference's own batchnorm.py, archs.up_conv, xresidualblock.py, spectral_norm.py and
+    efficientnet_pytorch (all import as-is)."""
+    import batchnorm as ref_bn, xresidualblock as ref_x, spectral_norm as ref_sn, efficientnet_pytorch as ref_e
+    archs = mods[0]
+    g = torch.Generator().manual_seed(21)
+    data = {}
+    # A9: _compute_mean_std on reduced sums of two "replicas" + the fused output formula (batchnorm.py:75,115-127)
+    torch.manual_seed(31)
+    bn = ref_bn.SynchronizedBatchNorm2d(8)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(8, generator=g) + 0.5); bn.bias.copy_(torch.randn(8, generator=g))
+    xa = torch.randn(2, 8, 6, 6, generator=g) * 2 + 1; xb = torch.randn(2, 8, 6, 6, generator=g) * 2 + 1
+    parts = [xa.view(2, 8, -1), xb.view(2, 8, -1)]
+    s = sum(p.sum(dim=0).sum(dim=-1) for p in parts); ss = sum((p ** 2).sum(dim=0).sum(dim=-1) for p in parts)
+    mean, inv_std = bn._compute_mean_std(s, ss, 2 * 2 * 36)
+    ya = (xa - mean.view(1, 8, 1, 1)) * (inv_std * bn.weight).view(1, 8, 1, 1) + bn.bias.view(1, 8, 1, 1)
+    data.update(sbn_xa=xa.numpy(), sbn_xb=xb.numpy(), sbn_w=bn.weight.detach().numpy(), sbn_b=bn.bias.detach().numpy(),
+                sbn_mean=mean.numpy(), sbn_inv_std=inv_std.numpy(), sbn_ya=ya.detach().numpy(),
+                sbn_running_mean=bn.running_mean.numpy(), sbn_running_var=bn.running_var.numpy())
+    # A13: up_conv
+    torch.manual_seed(32)
+    m = archs.up_conv(16, 8); m.train()
+    x = torch.randn(2, 16, 5, 6, generator=g)
+    y, dy, dx, gd = _grad_pack(m, x)
+    data.update(up_x=x.numpy(), up_y=y, up_dy=dy, up_dx=dx, up_gd=gd)
+    # A11: xResidualBlock (64 channels as in SURVEY 8a, and a small one)
+    for tag, (c, hw) in dict(xr_a=(16, 12), xr_b=(64, 10)).items():
+        torch.manual_seed(33)
+        m = ref_x.xResidualBlock(c, c); m.train()
+        x = torch.randn(2, c, hw, hw, generator=g)
+        y, dy, dx, gd = _grad_pack(m, x)
+        data.update({tag + '_x': x.numpy(), tag + '_y': y, tag + '_dy': dy, tag + '_dx': dx, tag + '_gd': gd,
+                     tag + '_cfg': np.array([c, hw]), tag + '_nparams': np.array(sum(p.numel() for p in m.parameters()))})
+    # A12: spectral_norm on a conv: u/v/sigma/weight after 1 and 2 training forwards, eval forward, grads
+    torch.manual_seed(34)
+    conv = ref_sn.spectral_norm(nn.Conv2d(8, 12, 3, padding=1))
+    x = torch.randn(2, 8, 6, 6, generator=g)
+    data.update(sn_x=x.numpy(), sn_w_orig=conv.weight_orig.detach().numpy().copy(), sn_u0=conv.weight_u.numpy().copy(),
+                sn_v0=conv.weight_v.numpy().copy(), sn_bias=conv.bias.detach().numpy().copy())
+    conv.train()
+    for it in (1, 2):
+        xr = x.clone().requires_grad_(True)
+        conv.zero_grad()
+        y = conv(xr)
+        dyv = torch.randn(y.shape, generator=torch.Generator().manual_seed(99))
+        y.backward(dyv)
+        data.update({'sn_y%d' % it: y.detach().numpy(), 'sn_u%d' % it: conv.weight_u.numpy().copy(), 'sn_v%d' % it: conv.weight_v.numpy().copy(),
+                     'sn_w%d' % it: conv.weight.detach().numpy().copy(), 'sn_dworig%d' % it: conv.weight_orig.grad.numpy().copy(),
+                     'sn_dx%d' % it: xr.grad.numpy().copy()})
+    data['sn_dy'] = dyv.numpy()
+    conv.eval()
+    data['sn_y_eval'] = conv(x).detach().numpy()
+    # A10: MBConvBlock variants (train mode, drop_connect off) + EfficientNet-B0 extract_features on a small image
+    from efficientnet_pytorch.utils import BlockArgs, GlobalParams
+    gp = GlobalParams(batch_norm_momentum=0.99, batch_norm_epsilon=1e-3, dropout_rate=0.2, num_classes=10, width_coefficient=1.0,
+                      depth_coefficient=1.0, depth_divisor=8, min_depth=None, drop_connect_rate=0.2, image_size=224)
+    cases = dict(mb_a=(3, 1, 16, 16, 1, 12), mb_b=(3, 2, 16, 24, 6, 12), mb_c=(5, 2, 24, 40, 6, 11), mb_d=(5, 1, 40, 40, 6, 8))
+    for tag, (k, s_, inp, out, e, hw) in cases.items():
+        torch.manual_seed(35)
+        ba = BlockArgs(kernel_size=k, num_repeat=1, input_filters=inp, output_filters=out, expand_ratio=e, id_skip=True,
+                       stride=[s_], se_ratio=0.25)
+        m = ref_e.model.MBConvBlock(ba, gp); m.train()
+        x = torch.randn(2, inp, hw, hw, generator=g)
+        y, dy, dx, gd = _grad_pack(m, x)
+        data.update({tag + '_x': x.numpy(), tag + '_y': y, tag + '_dy': dy, tag + '_dx': dx, tag + '_gd': gd,
+                     tag + '_cfg': np.array([k, s_, inp, out, e, hw]), tag + '_bufs': buffer_digests(m)})
+    torch.manual_seed(36)
+    net = ref_e.EfficientNet.from_name('efficientnet-b0', override_params=dict(drop_connect_rate=0.0)); net.train()
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    xr = x.clone().requires_grad_(True)
+    f = net.extract_features(xr)
+    dyf = torch.randn(f.shape, generator=torch.Generator().manual_seed(99))
+    f.backward(dyf)
+    feat_params = [p for n_, p in net.named_parameters() if not n_.startswith('_fc')]
+    data.update(eff_x=x.numpy(), eff_feat=f.detach().numpy(), eff_dy=dyf.numpy(), eff_dx=xr.grad.numpy(),
+                eff_gd=np.stack([digest(p.grad) for p in feat_params]), eff_init=np.stack([digest(p) for p in net.parameters()]),
+                eff_keys=np.array(list(net.state_dict().keys())))
+    net.eval()
+    with torch.no_grad():
+        data['eff_feat_eval'] = net.extract_features(x).numpy()
+    np.savez_compressed(os.path.join(OUT, 'unwired.npz'), **data)
+    print('unwired.npz written,', len(data), 'arrays')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
@@ -214,6 +300,8 @@ def main():
     mods = import_reference()
     if a.only in (None, 'blocks'):
         gen_blocks(mods)
+    if a.only in (None, 'unwired'):
+        gen_unwired(mods)
     if a.only in (None, 'step64'):
         gen_step(mods, 'step_n2_64', 2, 64, 64, steps=2)
     if a.only in (None, 'step256'):

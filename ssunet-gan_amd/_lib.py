@@ -97,6 +97,20 @@ SIGNATURES = {
     'ssg_clamp_adam_multi_f32': [_P, _P, _P, _P, _I, _F, _D, _D, _D, _D, _D, _D, _D, _P],
     'ssg_clamp_f32': [_P, _L, _F, _F, _P],
     'ssg_channel_sum_f32': [_P, _L, _I, _I, _P, _P, _P],
+    'ssg_dwconv2d_fwd_f32': [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    'ssg_dwconv2d_dgrad_f32': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    'ssg_dwconv2d_wgrad_workspace_bytes': [_I, _I, _I, _I, _I, _I],
+    'ssg_dwconv2d_wgrad_f32': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    'ssg_unary_fwd_f32': [_P, _I, _L, _I, _I, _P, _I, _P],
+    'ssg_unary_bwd_f32': [_P, _I, _P, _I, _L, _I, _I, _P, _I, _P],
+    'ssg_mul_fwd_f32': [_P, _I, _P, _I, _L, _I, _P, _I, _P],
+    'ssg_mul_bwd_f32': [_P, _I, _P, _I, _P, _I, _L, _I, _P, _I, _P, _I, _P],
+    'ssg_channel_scale_fwd_f32': [_P, _I, _P, _I, _L, _I, _P, _I, _P],
+    'ssg_sample_channel_sum_f32': [_P, _I, _P, _I, _I, _L, _I, _F, _P, _P],
+    'ssg_broadcast_rows_f32': [_P, _I, _L, _I, _F, _P, _I, _P],
+    'ssg_spectral_norm_workspace_bytes': [_I, _I],
+    'ssg_spectral_norm_fwd_f32': [_P, _I, _I, _P, _P, _I, _D, _P, _P, _P, _P],
+    'ssg_spectral_norm_bwd_f32': [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     'ssg_tool_mfma_peak_f32': [_P, _I, _I, _P],
     'ssg_tool_copy_f32': [_P, _P, _L, _P],
 }
@@ -104,6 +118,8 @@ _RESTYPES = {
     'ssg_conv2d_wgrad_workspace_bytes': C.c_int64,
     'ssg_bn_workspace_bytes': C.c_int64,
     'ssg_seg_loss_workspace_bytes': C.c_int64,
+    'ssg_dwconv2d_wgrad_workspace_bytes': C.c_int64,
+    'ssg_spectral_norm_workspace_bytes': C.c_int64,
 }
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_igemm_mtiles', 'ssg_conv2d_kernel_id', 'ssg_conv2d_wgrad_kernel_id'}
 

@@ -50,6 +50,37 @@ class BasicBlock(nn.Module):
         return ops.batch_norm_act(y, self.bn2, res=r, act=ACT_RELU)
 
 
+class conv_block(nn.Module):
+    """archs.py:831-846: (conv3x3 + bias -> BN -> ReLU) x 2."""
+
+    def __init__(self, ch_in, ch_out):
+        super().__init__()
+        self.conv = nn.Sequential(
+            nn.Conv2d(ch_in, ch_out, kernel_size=3, stride=1, padding=1, bias=True), nn.BatchNorm2d(ch_out), nn.ReLU(inplace=True),
+            nn.Conv2d(ch_out, ch_out, kernel_size=3, stride=1, padding=1, bias=True), nn.BatchNorm2d(ch_out), nn.ReLU(inplace=True))
+
+    def forward(self, x, x2=None):
+        c = self.conv
+        y = ops.conv2d(x, c[0].weight, c[0].bias, 1, 1, x2=x2)
+        y = ops.batch_norm_act(y, c[1], act=ACT_RELU, group=_sync_group(c[1]))
+        y = ops.conv2d(y, c[3].weight, c[3].bias, 1, 1)
+        return ops.batch_norm_act(y, c[4], act=ACT_RELU, group=_sync_group(c[4]))
+
+
+class up_conv(nn.Module):
+    """archs.py:848-860: nearest x2 -> conv3x3 + bias -> BN -> ReLU."""
+
+    def __init__(self, ch_in, ch_out):
+        super().__init__()
+        self.up = nn.Sequential(nn.Upsample(scale_factor=2), nn.Conv2d(ch_in, ch_out, kernel_size=3, stride=1, padding=1, bias=True),
+                                nn.BatchNorm2d(ch_out), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        y = ops.upsample2x_nearest(x)
+        y = ops.conv2d(y, self.up[1].weight, self.up[1].bias, 1, 1)
+        return ops.batch_norm_act(y, self.up[2], act=ACT_RELU, group=_sync_group(self.up[2]))
+
+
 class UNet_R_SS_v2(nn.Module):
     """archs.py:559-671: six-level residual U-Net with self-conditioned SPADE after every block,
     max-unpooling with the encoder's indices for the three deepest decoder stages and bilinear

@@ -1,0 +1,327 @@
+// Depthwise convolution + the element-wise pieces of the (unwired) MBConv / xResidualBlock ops for
+// gfx950.  All HBM-bound: one thread per 16-byte channel quad of one pixel, taps walked in
+// registers, weights read from the reference's [C][1][KH][KW] parameter (L1/L2 resident).
+// ABI + reference citations: include/ssunet_hip.h (ssg_dwconv2d_*, ssg_unary_*, ssg_mul_*,
+// ssg_channel_scale_*, ssg_global_avgpool_*).
+#include "common.h"
+
+namespace {
+
+int elem_grid(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+#define GRID_STRIDE(i, total) \
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (total); i += (long long)gridDim.x * 256)
+
+struct DwArgs {
+  const float* in; const float* w; const float* bias; const float* dout; float* out;
+  int N, H, W, C, ld, KH, KW, stride, pt, pl, OH, OW, ldo;
+};
+
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const DwArgs a) {
+  const int CQ = a.C / 4, KK = a.KH * a.KW;
+  const long long total = (long long)a.N * a.OH * a.OW * CQ;
+  GRID_STRIDE(i, total) {
+    const int cq = (int)(i % CQ); long long r = i / CQ;
+    const int ox = (int)(r % a.OW); r /= a.OW;
+    const int oy = (int)(r % a.OH); const int n = (int)(r / a.OH);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) acc = *(const f32x4*)(a.bias + 4 * cq);
+    const float* wp = a.w + (size_t)4 * cq * KK;
+    for (int ky = 0; ky < a.KH; ++ky) {
+      const int iy = oy * a.stride + ky - a.pt;
+      if ((unsigned)iy >= (unsigned)a.H) continue;
+      for (int kx = 0; kx < a.KW; ++kx) {
+        const int ix = ox * a.stride + kx - a.pl;
+        if ((unsigned)ix >= (unsigned)a.W) continue;
+        const f32x4 v = *(const f32x4*)(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.ld + 4 * cq);
+        const int t = ky * a.KW + kx;
+        acc[0] += v[0] * wp[t]; acc[1] += v[1] * wp[KK + t]; acc[2] += v[2] * wp[2 * KK + t]; acc[3] += v[3] * wp[3 * KK + t];
+      }
+    }
+    *(f32x4*)(a.out + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.ldo + 4 * cq) = acc;
+  }
+}
+
+// dx[n,y,x,c] = sum_{ky,kx} dout[n,(y+pt-ky)/s,(x+pl-kx)/s,c] * w[c,ky,kx]  (where divisible, in range)
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwArgs a) {
+  const int CQ = a.C / 4, KK = a.KH * a.KW;
+  const long long total = (long long)a.N * a.H * a.W * CQ;
+  GRID_STRIDE(i, total) {
+    const int cq = (int)(i % CQ); long long r = i / CQ;
+    const int x = (int)(r % a.W); r /= a.W;
+    const int y = (int)(r % a.H); const int n = (int)(r / a.H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* wp = a.w + (size_t)4 * cq * KK;
+    for (int ky = 0; ky < a.KH; ++ky) {
+      const int ty = y + a.pt - ky;
+      if (ty < 0 || ty % a.stride) continue;
+      const int oy = ty / a.stride;
+      if (oy >= a.OH) continue;
+      for (int kx = 0; kx < a.KW; ++kx) {
+        const int tx = x + a.pl - kx;
+        if (tx < 0 || tx % a.stride) continue;
+        const int ox = tx / a.stride;
+        if (ox >= a.OW) continue;
+        const f32x4 g = *(const f32x4*)(a.dout + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.ldo + 4 * cq);
+        const int t = ky * a.KW + kx;
+        acc[0] += g[0] * wp[t]; acc[1] += g[1] * wp[KK + t]; acc[2] += g[2] * wp[2 * KK + t]; acc[3] += g[3] * wp[3 * KK + t];
+      }
+    }
+    *(f32x4*)(a.out + ((size_t)(n * a.H + y) * a.W + x) * a.ld + 4 * cq) = acc;
+  }
+}
+
+// dw[c, t] = sum_pixels dout[p, c] * in[p*s + t, c]: column reduction per tap.  grid = (parts, channel
+// groups, taps); fp64 block combine; ordered second stage (deterministic).
+constexpr int DW_TQ = 16;                 // channel quads per block row
+__global__ __launch_bounds__(256) void dw_wgrad_partial_kernel(const DwArgs a, long long rows_per_part, double* __restrict__ part) {
+  __shared__ double red[256][4];
+  const int tid = threadIdx.x, tq = tid % DW_TQ, pr = tid / DW_TQ, PR = 256 / DW_TQ;
+  const int CQ = a.C / 4, cq = blockIdx.y * DW_TQ + tq;
+  const int t = blockIdx.z, ky = t / a.KW, kx = t - ky * a.KW;
+  const long long P = (long long)a.N * a.OH * a.OW;
+  const long long p0 = (long long)blockIdx.x * rows_per_part;
+  long long p1 = p0 + rows_per_part; if (p1 > P) p1 = P;
+  double s[4] = {0, 0, 0, 0};
+  if (cq < CQ) {
+    for (long long p = p0 + pr; p < p1; p += PR) {
+      const int ox = (int)(p % a.OW); const long long r = p / a.OW;
+      const int oy = (int)(r % a.OH); const int n = (int)(r / a.OH);
+      const int iy = oy * a.stride + ky - a.pt, ix = ox * a.stride + kx - a.pl;
+      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+        const f32x4 g = *(const f32x4*)(a.dout + (size_t)p * a.ldo + 4 * cq);
+        const f32x4 v = *(const f32x4*)(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.ld + 4 * cq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += (double)g[e] * (double)v[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[tid][e] = s[e];
+  __syncthreads();
+  if (pr == 0 && cq < CQ) {
+    double tot[4] = {0, 0, 0, 0};
+    for (int r = 0; r < PR; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tot[e] += red[r * DW_TQ + tq][e];
+    double* dst = part + ((size_t)blockIdx.x * gridDim.z + t) * a.C + 4 * cq;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[e] = tot[e];
+  }
+}
+__global__ void dw_wgrad_final_kernel(const double* __restrict__ part, int parts, int KK, int C, float* __restrict__ dw) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // over KK*C, idx = t*C + c
+  if (idx >= KK * C) return;
+  double s = 0;
+  for (int b = 0; b < parts; ++b) s += part[(size_t)b * KK * C + idx];
+  const int t = idx / C, c = idx - t * C;
+  dw[(size_t)c * KK + t] = (float)s;
+}
+
+// ---------------------------------------------------------------- unary ops (fwd / bwd)
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void unary_fwd_kernel(const float* __restrict__ x, int ldx, long long P, int C, int op, float* __restrict__ y, int ldy) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, P * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    const f32x4 v = *(const f32x4*)(x + p * ldx + 4 * cq);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = v[e];
+      o[e] = op == SSG_UNARY_SWISH ? z * sigm(z) : (op == SSG_UNARY_SIGMOID ? sigm(z) : expf(-(z * z)));
+    }
+    *(f32x4*)(y + p * ldy + 4 * cq) = o;
+  }
+}
+__global__ __launch_bounds__(256) void unary_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+                                                        long long P, int C, int op, float* __restrict__ dx, int lddx) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, P * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    const f32x4 v = *(const f32x4*)(x + p * ldx + 4 * cq);
+    const f32x4 g = *(const f32x4*)(dy + p * lddy + 4 * cq);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = v[e];
+      float d;
+      if (op == SSG_UNARY_SWISH) { const float s = sigm(z); d = s * (1.f + z * (1.f - s)); }      // utils.py:45-48
+      else if (op == SSG_UNARY_SIGMOID) { const float s = sigm(z); d = s * (1.f - s); }
+      else d = -2.f * z * expf(-(z * z));                                                          // xresidualblock.py:5-7
+      o[e] = g[e] * d;
+    }
+    *(f32x4*)(dx + p * lddx + 4 * cq) = o;
+  }
+}
+__global__ __launch_bounds__(256) void mul_fwd_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                      long long P, int C, float* __restrict__ y, int ldy) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, P * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    *(f32x4*)(y + p * ldy + 4 * cq) = *(const f32x4*)(a + p * lda + 4 * cq) * *(const f32x4*)(b + p * ldb + 4 * cq);
+  }
+}
+__global__ __launch_bounds__(256) void mul_bwd_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                      const float* __restrict__ dy, int lddy, long long P, int C,
+                                                      float* __restrict__ da, int ldda, float* __restrict__ db, int lddb) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, P * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    const f32x4 g = *(const f32x4*)(dy + p * lddy + 4 * cq);
+    *(f32x4*)(da + p * ldda + 4 * cq) = g * *(const f32x4*)(b + p * ldb + 4 * cq);
+    *(f32x4*)(db + p * lddb + 4 * cq) = g * *(const f32x4*)(a + p * lda + 4 * cq);
+  }
+}
+
+// y[n,p,c] = x[n,p,c] * s[n,c]  (squeeze-excite gate / drop-connect scale); bwd: dx = g*s, ds = sum_p g*x
+__global__ __launch_bounds__(256) void chscale_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ s, long long S,
+                                                          int N, int C, float* __restrict__ y, int ldy) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, (long long)N * S * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    const int n = (int)(p / S);
+    *(f32x4*)(y + p * ldy + 4 * cq) = *(const f32x4*)(x + p * ldx + 4 * cq) * *(const f32x4*)(s + (size_t)n * C + 4 * cq);
+  }
+}
+// per-sample column reduction: out[n,c] = scale * sum_p a[n,p,c] * (b ? b[n,p,c] : 1)
+__global__ __launch_bounds__(256) void sample_colsum_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                            long long S, int C, float scale, float* __restrict__ out) {
+  __shared__ double red[256][4];
+  const int tid = threadIdx.x, tq = tid % DW_TQ, pr = tid / DW_TQ, PR = 256 / DW_TQ;
+  const int CQ = C / 4, cq = blockIdx.x * DW_TQ + tq, n = blockIdx.y;
+  double s[4] = {0, 0, 0, 0};
+  if (cq < CQ)
+    for (long long p = pr; p < S; p += PR) {
+      const size_t row = (size_t)n * S + p;
+      f32x4 v = *(const f32x4*)(a + row * lda + 4 * cq);
+      if (b) v = v * *(const f32x4*)(b + row * ldb + 4 * cq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[tid][e] = s[e];
+  __syncthreads();
+  if (pr == 0 && cq < CQ) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double t = 0;
+      for (int r = 0; r < PR; ++r) t += red[r * DW_TQ + tq][e];
+      out[(size_t)n * C + 4 * cq + e] = (float)(t * scale);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict__ s, long long S, int N, int C, float scale,
+                                                         float* __restrict__ y, int ldy) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, (long long)N * S * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    const int n = (int)(p / S);
+    *(f32x4*)(y + p * ldy + 4 * cq) = scale * *(const f32x4*)(s + (size_t)n * C + 4 * cq);
+  }
+}
+
+int dw_check(const char* what, const float* in, int N, int H, int W, int C, int ld, int KH, int KW, int stride) {
+  SSG_REQUIRE(in && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C, SSG_EINVAL, "%s: bad tensor", what);
+  SSG_REQUIRE(KH >= 1 && KH <= 11 && KW >= 1 && KW <= 11 && stride >= 1 && stride <= 4, SSG_EINVAL, "%s: kernel/stride", what);
+  return SSG_OK;
+}
+
+}  // namespace
+
+extern "C" int ssg_dwconv2d_fwd_f32(const float* in, int N, int H, int W, int C, int ld, const float* w, const float* bias, int KH, int KW,
+                                    int stride, int pad_top, int pad_left, int OH, int OW, float* out, int ldo, void* stream) {
+  int rc = dw_check("dwconv_fwd", in, N, H, W, C, ld, KH, KW, stride);
+  if (rc) return rc;
+  SSG_REQUIRE(w && out && OH > 0 && OW > 0 && ldo % 4 == 0, SSG_EINVAL, "dwconv_fwd: bad output");
+  DwArgs a{in, w, bias, nullptr, out, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, ldo};
+  hipLaunchKernelGGL(dw_fwd_kernel, dim3(elem_grid((long long)N * OH * OW * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+extern "C" int ssg_dwconv2d_dgrad_f32(const float* dout, int lddo, int N, int H, int W, int C, const float* w, int KH, int KW, int stride,
+                                      int pad_top, int pad_left, int OH, int OW, float* dx, int lddx, void* stream) {
+  int rc = dw_check("dwconv_dgrad", dout, N, OH, OW, C, lddo, KH, KW, stride);
+  if (rc) return rc;
+  SSG_REQUIRE(w && dx && H > 0 && W > 0 && lddx % 4 == 0, SSG_EINVAL, "dwconv_dgrad: bad output");
+  DwArgs a{nullptr, w, nullptr, dout, dx, N, H, W, C, lddx, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
+  hipLaunchKernelGGL(dw_dgrad_kernel, dim3(elem_grid((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+extern "C" int64_t ssg_dwconv2d_wgrad_workspace_bytes(int N, int OH, int OW, int C, int KH, int KW) {
+  long long P = (long long)N * OH * OW;
+  long long parts = (P + 255) / 256; if (parts > 256) parts = 256; if (parts < 1) parts = 1;
+  return parts * KH * KW * (int64_t)C * (int64_t)sizeof(double);
+}
+
+extern "C" int ssg_dwconv2d_wgrad_f32(const float* in, int N, int H, int W, int C, int ld, const float* dout, int lddo, int KH, int KW,
+                                      int stride, int pad_top, int pad_left, int OH, int OW, float* dw, void* ws, void* stream) {
+  int rc = dw_check("dwconv_wgrad", in, N, H, W, C, ld, KH, KW, stride);
+  if (rc) return rc;
+  SSG_REQUIRE(dout && dw && ws && OH > 0 && OW > 0, SSG_EINVAL, "dwconv_wgrad: bad args");
+  const long long P = (long long)N * OH * OW;
+  long long parts = (P + 255) / 256; if (parts > 256) parts = 256; if (parts < 1) parts = 1;
+  const long long rpp = (P + parts - 1) / parts;
+  parts = (P + rpp - 1) / rpp;
+  DwArgs a{in, nullptr, nullptr, dout, nullptr, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dw_wgrad_partial_kernel, dim3((unsigned)parts, (unsigned)((C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)(KH * KW)), dim3(256), 0, st,
+                     a, rpp, (double*)ws);
+  SSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dw_wgrad_final_kernel, dim3((unsigned)((KH * KW * C + 127) / 128)), dim3(128), 0, st, (const double*)ws, (int)parts, KH * KW, C, dw);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+extern "C" int ssg_unary_fwd_f32(const float* x, int ldx, int64_t P, int C, int op, float* y, int ldy, void* stream) {
+  SSG_REQUIRE(x && y && P > 0 && C > 0 && C % 4 == 0 && op >= 0 && op <= 2, SSG_EINVAL, "unary_fwd: bad args");
+  hipLaunchKernelGGL(unary_fwd_kernel, dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, (long long)P, C, op, y, ldy);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_unary_bwd_f32(const float* x, int ldx, const float* dy, int lddy, int64_t P, int C, int op, float* dx, int lddx, void* stream) {
+  SSG_REQUIRE(x && dy && dx && P > 0 && C > 0 && C % 4 == 0 && op >= 0 && op <= 2, SSG_EINVAL, "unary_bwd: bad args");
+  hipLaunchKernelGGL(unary_bwd_kernel, dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, (long long)P, C, op, dx, lddx);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_mul_fwd_f32(const float* a, int lda, const float* b, int ldb, int64_t P, int C, float* y, int ldy, void* stream) {
+  SSG_REQUIRE(a && b && y && P > 0 && C > 0 && C % 4 == 0, SSG_EINVAL, "mul_fwd: bad args");
+  hipLaunchKernelGGL(mul_fwd_kernel, dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, (long long)P, C, y, ldy);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_mul_bwd_f32(const float* a, int lda, const float* b, int ldb, const float* dy, int lddy, int64_t P, int C,
+                               float* da, int ldda, float* db, int lddb, void* stream) {
+  SSG_REQUIRE(a && b && dy && da && db && P > 0 && C > 0 && C % 4 == 0, SSG_EINVAL, "mul_bwd: bad args");
+  hipLaunchKernelGGL(mul_bwd_kernel, dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, dy, lddy, (long long)P, C, da, ldda, db, lddb);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_channel_scale_fwd_f32(const float* x, int ldx, const float* s, int N, int64_t S, int C, float* y, int ldy, void* stream) {
+  SSG_REQUIRE(x && s && y && N > 0 && S > 0 && C > 0 && C % 4 == 0, SSG_EINVAL, "channel_scale: bad args");
+  hipLaunchKernelGGL(chscale_fwd_kernel, dim3(elem_grid((long long)N * S * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, s, (long long)S, N, C, y, ldy);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_sample_channel_sum_f32(const float* a, int lda, const float* b, int ldb, int N, int64_t S, int C, float scale, float* out, void* stream) {
+  SSG_REQUIRE(a && out && N > 0 && S > 0 && C > 0 && C % 4 == 0, SSG_EINVAL, "sample_channel_sum: bad args");
+  hipLaunchKernelGGL(sample_colsum_kernel, dim3((unsigned)((C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)N), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                     (long long)S, C, scale, out);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_broadcast_rows_f32(const float* s, int N, int64_t S, int C, float scale, float* y, int ldy, void* stream) {
+  SSG_REQUIRE(s && y && N > 0 && S > 0 && C > 0 && C % 4 == 0, SSG_EINVAL, "broadcast_rows: bad args");
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3(elem_grid((long long)N * S * (C / 4))), dim3(256), 0, (hipStream_t)stream, s, (long long)S, N, C, scale, y, ldy);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}

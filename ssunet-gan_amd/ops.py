@@ -18,7 +18,8 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvDesc, WgradDesc, call, ptr,
 
 __all__ = ['conv2d', 'batch_norm_act', 'max_pool2x2', 'max_unpool2x2', 'upsample2x_bilinear', 'upsample2x_nearest',
            'spade_modulate', 'adaptive_avgpool_flat', 'linear', 'seg_loss', 'bce_with_logits_const', 'nan_to_zero_',
-           'to_nhwc', 'new_nhwc', 'bump_weight_epoch']
+           'to_nhwc', 'new_nhwc', 'bump_weight_epoch', 'dwconv2d', 'swish', 'sigmoid', 'gaussian', 'mul', 'global_avgpool',
+           'channel_scale', 'spectral_norm_weight']
 
 
 def pad4(c):
@@ -115,8 +116,17 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+def _pad4(pad):
+    """int (symmetric) or (top, bottom, left, right) -> (pt, pb, pl, pr)."""
+    if isinstance(pad, (tuple, list)):
+        pt, pb, pl, pr = [int(v) for v in pad]
+        return pt, pb, pl, pr
+    return int(pad), int(pad), int(pad), int(pad)
+
+
 def _taps_fwd(kh, kw, pad):
-    return [(ky, kx, ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
+    pt, _, pl, _ = _pad4(pad)
+    return [(ky, kx, ky - pt, kx - pl) for ky in range(kh) for kx in range(kw)]
 
 
 def _pack(weight, transpose, taps, cred_pad, c1_for_mode):
@@ -224,6 +234,11 @@ def _out_size(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
+def _out_hw(h, w, kh, kw, s, pad):
+    pt, pb, pl, pr = _pad4(pad)
+    return (h + pt + pb - kh) // s + 1, (w + pl + pr - kw) // s + 1
+
+
 def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=None):
     o, i, kh, kw = weight.shape
     n, c1, h, w = x1.shape
@@ -235,7 +250,7 @@ def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=
     cred_pad = pad4(c1) + pad4(c2)
     taps = _taps_fwd(kh, kw, pad)
     wpk, kp, kmode = _pack(weight, 0, taps, cred_pad, pad4(c1))
-    oh, ow = _out_size(h, kh, stride, pad), _out_size(w, kw, stride, pad)
+    oh, ow = _out_hw(h, w, kh, kw, stride, pad)
     if out is None:
         out = new_nhwc(n, o, oh, ow, x1.device)
     _conv_launch(x1, x2, wpk, kp, kmode, 0, o, bias, res, act, slope, taps, n, h, w, oh, ow, oh, ow, stride, 1, 0, 0, out)
@@ -248,9 +263,10 @@ def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None):
     o, i, kh, kw = weight.shape
     n, _, oh, ow = dy.shape
     cred_pad = pad4(o)
+    pt, _, pl, _ = _pad4(pad)
     dx = new_nhwc(n, c_hi - c_lo, h, w, dy.device)
     if stride == 1:
-        taps = [(ky, kx, pad - ky, pad - kx) for ky in range(kh) for kx in range(kw)]
+        taps = [(ky, kx, pt - ky, pl - kx) for ky in range(kh) for kx in range(kw)]
         wpk, kp, kmode = _pack(weight, 1, taps, cred_pad, cred_pad)
         _conv_launch(dy, None, wpk, kp, kmode, c_lo, c_hi - c_lo, None, res, ACT_NONE, 0.0, taps, n, oh, ow, h, w, h, w, 1, 1, 0, 0, dx)
         return dx
@@ -260,8 +276,8 @@ def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None):
     classes = []
     for py in range(s):
         for px in range(s):
-            taps = [(ky, kx, (py + pad - ky) // s, (px + pad - kx) // s) for ky in range(kh) for kx in range(kw)
-                    if (py + pad - ky) % s == 0 and (px + pad - kx) % s == 0]
+            taps = [(ky, kx, (py + pt - ky) // s, (px + pl - kx) // s) for ky in range(kh) for kx in range(kw)
+                    if (py + pt - ky) % s == 0 and (px + pl - kx) % s == 0]
             classes.append((py, px, taps))
     if any(len(t) == 0 for _, _, t in classes):
         dx.zero_()
@@ -359,8 +375,11 @@ class _Conv2d(torch.autograd.Function):
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, x2=None):
+    """F.conv2d on the HIP kernels.  `padding`: int or (top, bottom, left, right) (TF-"same" static
+    padding of the EfficientNet convs is asymmetric); `x2`: second tensor concatenated after x."""
     _lib.require_gpu(x)
-    return _Conv2d.apply(x, x2, weight, bias, int(stride), int(padding), int(act), float(slope))
+    pad = tuple(int(v) for v in padding) if isinstance(padding, (tuple, list)) else int(padding)
+    return _Conv2d.apply(x, x2, weight, bias, int(stride), pad, int(act), float(slope))
 
 
 # ----------------------------------------------------------------------------- linear (as 1x1 conv over a 1 x N "image")
@@ -799,3 +818,234 @@ def nan_to_zero_(x):
     """x[isnan(x)] = 0 in place, differentiable (train_seg_gan.py:190)."""
     _lib.require_gpu(x)
     return _NanToZero.apply(x)
+
+
+# ----------------------------------------------------------------------------- depthwise conv (unwired rows A10/A11)
+class _DwConv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        if c % 4 or weight.shape[0] != c or weight.shape[1] != 1:
+            raise ValueError('dwconv2d: depthwise weight [C,1,KH,KW] with C %% 4 == 0 expected, got %s for C=%d' % (tuple(weight.shape), c))
+        kh, kw = weight.shape[2:]
+        pt, pb, pl, pr = _pad4(pad)
+        oh, ow = _out_hw(h, w, kh, kw, stride, pad)
+        y = new_nhwc(n, c, oh, ow, x.device)
+        wc = weight.contiguous()
+        call('ssg_dwconv2d_fwd_f32', ptr(x), n, h, w, c, _ld(x), ptr(wc), ptr(bias), kh, kw, stride, pt, pl, oh, ow, ptr(y), _ld(y), stream_ptr())
+        ctx.save_for_backward(x, wc)
+        ctx.cfg = (stride, pt, pl, oh, ow, bias is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, wc = ctx.saved_tensors
+        stride, pt, pl, oh, ow, has_bias = ctx.cfg
+        dy = to_nhwc(dy)
+        n, c, h, w = x.shape
+        kh, kw = wc.shape[2:]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = new_nhwc(n, c, h, w, x.device)
+            call('ssg_dwconv2d_dgrad_f32', ptr(dy), _ld(dy), n, h, w, c, ptr(wc), kh, kw, stride, pt, pl, oh, ow, ptr(dx), _ld(dx), stream_ptr())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(wc)
+            ws = _ws(call('ssg_dwconv2d_wgrad_workspace_bytes', n, oh, ow, c, kh, kw), x.device)
+            call('ssg_dwconv2d_wgrad_f32', ptr(x), n, h, w, c, _ld(x), ptr(dy), _ld(dy), kh, kw, stride, pt, pl, oh, ow, ptr(dw), ptr(ws), stream_ptr())
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sum(dy, c)
+        return dx, dw, db, None, None
+
+
+def dwconv2d(x, weight, bias=None, stride=1, padding=0):
+    """Depthwise F.conv2d (groups = C)."""
+    _lib.require_gpu(x)
+    pad = tuple(int(v) for v in padding) if isinstance(padding, (tuple, list)) else int(padding)
+    return _DwConv2d.apply(x, weight, bias, int(stride), pad)
+
+
+UNARY_SWISH, UNARY_SIGMOID, UNARY_GAUSSIAN = 0, 1, 2
+
+
+class _Unary(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = new_nhwc(n, c, h, w, x.device)
+        call('ssg_unary_fwd_f32', ptr(x), _ld(x), n * h * w, pad4(c), op, ptr(y), _ld(y), stream_ptr())
+        ctx.save_for_backward(x)
+        ctx.op = op
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        n, c, h, w = x.shape
+        dx = new_nhwc(n, c, h, w, x.device)
+        call('ssg_unary_bwd_f32', ptr(x), _ld(x), ptr(dy), _ld(dy), n * h * w, pad4(c), ctx.op, ptr(dx), _ld(dx), stream_ptr())
+        return dx, None
+
+
+def swish(x):
+    """x * sigmoid(x) with the reference's hand-written backward (efficientnet_pytorch/utils.py:37-48)."""
+    _lib.require_gpu(x)
+    return _Unary.apply(x, UNARY_SWISH)
+
+
+def sigmoid(x):
+    _lib.require_gpu(x)
+    return _Unary.apply(x, UNARY_SIGMOID)
+
+
+def gaussian(x):
+    """exp(-x*x) (xresidualblock.py:5-7)."""
+    _lib.require_gpu(x)
+    return _Unary.apply(x, UNARY_GAUSSIAN)
+
+
+class _Mul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = to_nhwc(a); b = to_nhwc(b)
+        n, c, h, w = a.shape
+        y = new_nhwc(n, c, h, w, a.device)
+        call('ssg_mul_fwd_f32', ptr(a), _ld(a), ptr(b), _ld(b), n * h * w, pad4(c), ptr(y), _ld(y), stream_ptr())
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        n, c, h, w = a.shape
+        da = new_nhwc(n, c, h, w, a.device); db = new_nhwc(n, c, h, w, a.device)
+        call('ssg_mul_bwd_f32', ptr(a), _ld(a), ptr(b), _ld(b), ptr(dy), _ld(dy), n * h * w, pad4(c),
+             ptr(da), _ld(da), ptr(db), _ld(db), stream_ptr())
+        return da, db
+
+
+def mul(a, b):
+    _lib.require_gpu(a)
+    return _Mul.apply(a, b)
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        if c % 4:
+            raise ValueError('global_avgpool: C %% 4 != 0')
+        y = new_nhwc(n, c, 1, 1, x.device)
+        call('ssg_sample_channel_sum_f32', ptr(x), _ld(x), None, 0, n, h * w, c, 1.0 / (h * w), ptr(y), stream_ptr())
+        ctx.cfg = (n, c, h, w)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        n, c, h, w = ctx.cfg
+        dy = to_nhwc(dy)
+        dx = new_nhwc(n, c, h, w, dy.device)
+        call('ssg_broadcast_rows_f32', ptr(dy), n, h * w, c, 1.0 / (h * w), ptr(dx), _ld(dx), stream_ptr())
+        return dx
+
+
+def global_avgpool(x):
+    """F.adaptive_avg_pool2d(x, 1) -> [N, C, 1, 1]."""
+    _lib.require_gpu(x)
+    return _GlobalAvgPool.apply(x)
+
+
+class _ChannelScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        x = to_nhwc(x); s = to_nhwc(s)
+        n, c, h, w = x.shape
+        if tuple(s.shape) != (n, c, 1, 1) or c % 4:
+            raise ValueError('channel_scale: gate %s does not match %s' % (tuple(s.shape), tuple(x.shape)))
+        y = new_nhwc(n, c, h, w, x.device)
+        call('ssg_channel_scale_fwd_f32', ptr(x), _ld(x), ptr(s), n, h * w, c, ptr(y), _ld(y), stream_ptr())
+        ctx.save_for_backward(x, s)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, s = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        n, c, h, w = x.shape
+        dx = new_nhwc(n, c, h, w, x.device)
+        call('ssg_channel_scale_fwd_f32', ptr(dy), _ld(dy), ptr(s), n, h * w, c, ptr(dx), _ld(dx), stream_ptr())
+        ds = new_nhwc(n, c, 1, 1, x.device)
+        call('ssg_sample_channel_sum_f32', ptr(dy), _ld(dy), ptr(x), _ld(x), n, h * w, c, 1.0, ptr(ds), stream_ptr())
+        return dx, ds
+
+
+def channel_scale(x, s):
+    """x * s with s of shape [N, C, 1, 1] (squeeze-excite gate, drop-connect mask)."""
+    _lib.require_gpu(x)
+    return _ChannelScale.apply(x, s)
+
+
+# ----------------------------------------------------------------------------- spectral norm (unwired row A12)
+class _SpectralNormWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, u, v, n_iter, eps):
+        wm = weight.contiguous()
+        rows = wm.shape[0]
+        cols = wm.numel() // rows
+        out = torch.empty_like(wm)
+        sigma = torch.empty((), dtype=torch.float32, device=wm.device)
+        ws = _ws(call('ssg_spectral_norm_workspace_bytes', rows, cols), wm.device)
+        call('ssg_spectral_norm_fwd_f32', ptr(wm), rows, cols, ptr(u), ptr(v), n_iter, float(eps), ptr(out), ptr(sigma), ptr(ws), stream_ptr())
+        # the reference clones u, v after the in-place iteration so backward sees this call's vectors
+        ctx.save_for_backward(wm, u.clone(), v.clone(), sigma)
+        ctx.mark_non_differentiable(sigma)
+        return out, sigma
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dwsn, _):
+        wm, u, v, sigma = ctx.saved_tensors
+        rows = wm.shape[0]
+        cols = wm.numel() // rows
+        dwsn = dwsn.contiguous()
+        dw = torch.empty_like(wm)
+        ws = _ws(call('ssg_spectral_norm_workspace_bytes', rows, cols), wm.device)
+        call('ssg_spectral_norm_bwd_f32', ptr(dwsn), ptr(wm), rows, cols, ptr(u), ptr(v), ptr(sigma), ptr(dw), ptr(ws), stream_ptr())
+        return dw, None, None, None, None
+
+
+def spectral_norm_weight(weight_orig, u, v, n_power_iterations=1, eps=1e-12):
+    """weight_orig / sigma after `n_power_iterations` in-place power-iteration updates of u, v."""
+    _lib.require_gpu(weight_orig)
+    return _SpectralNormWeight.apply(weight_orig, u, v, int(n_power_iterations), float(eps))
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = to_nhwc(a); b = to_nhwc(b)
+        n, c, h, w = a.shape
+        if _ld(a) != _ld(b) or a.shape != b.shape:
+            raise ValueError('add: shape/stride mismatch')
+        y = new_nhwc(n, c, h, w, a.device, ld=_ld(a))
+        call('ssg_add_f32', ptr(a), ptr(b), n * h * w * _ld(a), ptr(y), stream_ptr())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    """a + b for two NHWC tensors of the same shape."""
+    _lib.require_gpu(a)
+    return _Add.apply(a, b)
