@@ -224,6 +224,10 @@ int ssg_clamp_adam_multi_f32(const void* const* ptrs, const int64_t* sizes, cons
                              double beta2, double eps, double weight_decay, double bias_corr1,
                              double bias_corr2_sqrt, void* stream);
 int ssg_clamp_f32(float* x, int64_t n, float lo, float hi, void* stream);
+/* clamp member `which` (0 param, 1 grad, 2 exp_avg, 3 exp_avg_sq) of every record of `ptrs` in one
+ * launch -- stage 1 clamps the WEIGHTS to +-clip every step (train.py:111-112) */
+int ssg_clamp_multi_f32(const void* const* ptrs, const int64_t* sizes, const int32_t* blk_tensor, const int32_t* blk_chunk,
+                        int nblocks, int which, float lo, float hi, void* stream);
 
 /* per-channel sums over pixels: out[c] = sum_p x[p,c] (bias gradients) */
 int ssg_channel_sum_f32(const float* x, int64_t P, int C, int ld, float* out, void* ws, void* stream);

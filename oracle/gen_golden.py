@@ -205,6 +205,34 @@ def gen_blocks(mods):
     print('blocks.npz written,', len(data), 'arrays')
 
 
+def gen_stage1(mods):
+    """Stage-1 trainer (train.py:68-137) on the reference's UNet_R_SS_v2 + BCEDiceLoss: Adam(lr 1e-4,
+    weight_decay 1e-7) and the per-step weight clamp +-0.7 (config_v1.json:30-41); 2 steps at 2x3x64x64."""
+    archs, msg, losses, metrics, _ = mods
+    torch.manual_seed(41)
+    model = archs.UNet_R_SS_v2(3, 3, False)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-7)
+    crit = losses.BCEDiceLoss()
+    inp, tgt = synthetic_batch(2, 64, 64)
+    data = {}
+    model.train()
+    for s in range(2):
+        out = model(inp)
+        out[torch.isnan(out)] = 0
+        loss = crit(out, tgt)
+        iou = metrics.iou_score(out[:, 1:3].clone(), tgt[:, 1:3].clone()); dice = metrics.dice_coef(out[:, 1:3].clone(), tgt[:, 1:3].clone())
+        for p in model.parameters():
+            p.data.clamp_(-0.7, 0.7)
+        opt.zero_grad(); loss.backward()
+        data['s%d_grads' % s] = param_digests(model, True)
+        opt.step()
+        data['s%d_params' % s] = param_digests(model)
+        data['s%d_scalars' % s] = np.array([loss.item(), float(iou), float(dice)])
+        data['s%d_logits' % s] = out.detach().numpy().copy()
+        print('stage1 step', s, data['s%d_scalars' % s])
+    np.savez_compressed(os.path.join(OUT, 'stage1_n2_64.npz'), **data)
+
+
 def gen_unwired(mods):
     """Golden vectors for the named-but-unwired blocks, from the
     reference's own batchnorm.py, archs.up_conv, xresidualblock.py, spectral_norm.py and
@@ -302,6 +330,8 @@ def main():
         gen_blocks(mods)
     if a.only in (None, 'unwired'):
         gen_unwired(mods)
+    if a.only in (None, 'stage1'):
+        gen_stage1(mods)
     if a.only in (None, 'step64'):
         gen_step(mods, 'step_n2_64', 2, 64, 64, steps=2)
     if a.only in (None, 'step256'):

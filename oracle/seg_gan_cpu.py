@@ -272,3 +272,19 @@ def synthetic_batch(n, h, w, seed=7, num_classes=3):
     inp = torch.randn(n, 3, h, w, generator=g)
     tgt = (torch.rand(n, num_classes, h, w, generator=g) > 0.5).float()
     return inp, tgt
+
+
+def stage1_step(model, optimizer, inp, tgt, clip=0.7, num_classes=3):
+    """One iteration of train.py:79-115 (stage 1, deep_supervision off): forward, BCEDice, IoU/Dice on
+    channels 1:, THEN the weight clamp to +-clip (:111-112), zero_grad, backward, optimizer.step()."""
+    out = model(inp)
+    out[torch.isnan(out)] = 0
+    loss = bce_dice_loss(out, tgt)
+    iou = iou_score(out[:, 1:num_classes].clone(), tgt[:, 1:num_classes].clone())
+    dice = dice_coef(out[:, 1:num_classes].clone(), tgt[:, 1:num_classes].clone())
+    for p in model.parameters():
+        p.data.clamp_(-clip, clip)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return OrderedDict(loss=loss.item(), iou=float(iou), dice=float(dice), out=out.detach())

@@ -96,6 +96,7 @@ SIGNATURES = {
     'ssg_bce_logits_const_bwd_f32': [_P, _I, _I, _F, _P, _P, _I, _P],
     'ssg_clamp_adam_multi_f32': [_P, _P, _P, _P, _I, _F, _D, _D, _D, _D, _D, _D, _D, _P],
     'ssg_clamp_f32': [_P, _L, _F, _F, _P],
+    'ssg_clamp_multi_f32': [_P, _P, _P, _P, _I, _I, _F, _F, _P],
     'ssg_channel_sum_f32': [_P, _L, _I, _I, _P, _P, _P],
     'ssg_dwconv2d_fwd_f32': [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'ssg_dwconv2d_dgrad_f32': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],

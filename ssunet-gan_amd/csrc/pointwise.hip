@@ -124,6 +124,17 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(const void* const* __re
   }
 }
 
+__global__ __launch_bounds__(256) void clamp_multi_kernel(const void* const* __restrict__ ptrs, const long long* __restrict__ sizes,
+                                                          const int* __restrict__ blk_tensor, const int* __restrict__ blk_chunk, int stride,
+                                                          float lo, float hi) {
+  const int t = blk_tensor[blockIdx.x];
+  const long long base = (long long)blk_chunk[blockIdx.x] * ADAM_CHUNK;
+  float* P = (float*)ptrs[stride * t];
+  long long n = sizes[t] - base;
+  if (n > ADAM_CHUNK) n = ADAM_CHUNK;
+  for (int i = threadIdx.x; i < n; i += 256) { float v = P[base + i]; v = v < lo ? lo : v; v = v > hi ? hi : v; P[base + i] = v; }
+}
+
 }  // namespace
 
 extern "C" int ssg_spade_modulate_fwd_f32(const float* x, int ldx, const float* gb, int ldgb, int64_t P, int C, float* y, int ldy, void* stream) {
@@ -178,6 +189,18 @@ extern "C" int ssg_clamp_adam_multi_f32(const void* const* ptrs, const int64_t* 
   hipLaunchKernelGGL(clamp_adam_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, ptrs, (const long long*)sizes,
                      blk_tensor, blk_chunk, clip, (float)(lr / bias_corr1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
                      (float)weight_decay, (float)bias_corr2_sqrt);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+/* Clamp tensor number `which` (0 = param, 1 = grad, ...) of every 4-pointer record in `ptrs` (the
+ * layout ssg_clamp_adam_multi_f32 uses) to [lo, hi] in one launch: stage-1's per-step WEIGHT clamp
+ * (train.py:111-112). */
+extern "C" int ssg_clamp_multi_f32(const void* const* ptrs, const int64_t* sizes, const int32_t* blk_tensor, const int32_t* blk_chunk,
+                                   int nblocks, int which, float lo, float hi, void* stream) {
+  SSG_REQUIRE(ptrs && sizes && blk_tensor && blk_chunk && nblocks > 0 && which >= 0 && which < 4, SSG_EINVAL, "clamp_multi: bad args");
+  hipLaunchKernelGGL(clamp_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const void* const*)(ptrs + which),
+                     (const long long*)sizes, blk_tensor, blk_chunk, 4, lo, hi);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

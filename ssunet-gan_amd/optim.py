@@ -79,3 +79,29 @@ def clip_adam_step(optimizer, grad_clip=None):
              float(grad_clip) if grad_clip else 0.0, float(group['lr']), float(beta1), float(beta2), float(group['eps']),
              float(group['weight_decay']), bc1, bc2_sqrt, stream_ptr())
     ops.bump_weight_epoch()
+
+
+def clamp_parameters_(params, clip):
+    """`for p in params: p.data.clamp_(-clip, clip)` (train.py:111-112) in one multi-tensor launch."""
+    params = [p for p in params]
+    if not params:
+        return
+    key = ('clampw',) + tuple(p.data_ptr() for p in params)
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        ptrs, sizes, blk_t, blk_c = [], [], [], []
+        for t, p in enumerate(params):
+            _lib.require_gpu(p)
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise ValueError('clamp_parameters_: parameters must be contiguous fp32')
+            ptrs += [p.data_ptr(), 0, 0, 0]
+            sizes.append(p.numel())
+            for c in range((p.numel() + ADAM_CHUNK - 1) // ADAM_CHUNK):
+                blk_t.append(t); blk_c.append(c)
+        dev = params[0].device
+        plan = (torch.tensor(ptrs, dtype=torch.int64).to(dev), torch.tensor(sizes, dtype=torch.int64).to(dev),
+                torch.tensor(blk_t, dtype=torch.int32).to(dev), torch.tensor(blk_c, dtype=torch.int32).to(dev), len(blk_t))
+        _PLAN_CACHE[key] = plan
+    ptrs, sizes, blk_t, blk_c, nblk = plan
+    call('ssg_clamp_multi_f32', ptr(ptrs), ptr(sizes), ptr(blk_t), ptr(blk_c), nblk, 0, -float(clip), float(clip), stream_ptr())
+    ops.bump_weight_epoch()              # packed-weight caches must see the clamped values

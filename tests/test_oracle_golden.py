@@ -95,3 +95,18 @@ def test_nan_and_inf_guards():
     assert torch.isfinite(l) and abs(l.item() - 2 * dice.item()) < 1e-6
     y = torch.tensor([[float('nan'), 1.0]])
     assert O.iou_score(y, torch.tensor([[1.0, 1.0]])) == pytest.approx((1 + 1e-5) / (2 + 1e-5))
+
+
+def test_oracle_stage1_matches_reference():
+    """Stage-1 step (train.py:79-115): weight clamp between forward and backward, Adam with weight decay."""
+    g = np.load(os.path.join(GOLDEN, 'stage1_n2_64.npz'))
+    torch.manual_seed(41)
+    model = O.UNetRSSv2CPU(3, 3, False).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-7)
+    inp, tgt = O.synthetic_batch(2, 64, 64)
+    r = O.stage1_step(model, opt, inp, tgt)
+    assert np.abs(np.array([r['loss'], r['iou'], r['dice']]) - g['s0_scalars']).max() < 1e-6
+    assert np.abs(r['out'].numpy() - g['s0_logits']).max() < 1e-6
+    assert np.allclose(_digests(model.parameters())[:, 1], g['s0_params'][:, 1], rtol=1e-6, atol=1e-6)
+    r = O.stage1_step(model, opt, inp, tgt)
+    assert np.abs(np.array([r['loss'], r['iou'], r['dice']]) - g['s1_scalars']).max() < 1e-3
