@@ -185,6 +185,8 @@ int ssg_spade_modulate_bwd_f32(const float* x, int ldx, const float* gb, int ldg
                                float* dx, int lddx, float* dgb, int lddgb, void* stream);
 /* activation backward: dx = dy * (y > 0 ? 1 : slope) (+ add) */
 int ssg_act_bwd_f32(const float* y, int ldy, const float* dy, int lddy, int64_t P, int C, int act, float slope, float* dx, int lddx, void* stream);
+/* dst[p, 0:C] = src[p, 0:C]: channel-slice copy (materialised torch.cat of > 2 tensors, archs.py:910-925) */
+int ssg_copy_channels_f32(const float* src, int ldsrc, int64_t P, int C, float* dst, int lddst, void* stream);
 /* out = a + b (gradient accumulation across consumers) */
 int ssg_add_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
 /* x[isnan(x)] = 0 in place, mask[i] = 1 where it was NaN (train_seg_gan.py:190) */

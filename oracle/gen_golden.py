@@ -233,6 +233,35 @@ def gen_stage1(mods):
     np.savez_compressed(os.path.join(OUT, 'stage1_n2_64.npz'), **data)
 
 
+def gen_archs(mods):
+    """Every exported arch the build provides: logits, input gradient and
+    per-parameter gradient digests on 4 x 3 x 64 x 64 (large enough that the deepest batch norms see
+    >= 16 samples), seeds regenerate the weights."""
+    archs = mods[0]
+    data = {}
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    data['x'] = x.numpy()
+    for name, ds in (('UNet', False), ('NestedUNet', False), ('NestedUNet', True), ('SSUNet', False), ('UNet_ori', False),
+                     ('UNet_B_SS', False), ('UNet_R_SS', False)):
+        torch.manual_seed(52)
+        m = archs.__dict__[name](3, 3, ds); m.train()
+        xr = x.clone().requires_grad_(True)
+        out = m(xr)
+        outs = out if isinstance(out, list) else [out]
+        tot = 0
+        for i, o in enumerate(outs):
+            dy = torch.randn(o.shape, generator=torch.Generator().manual_seed(99 + i))
+            tot = tot + (o * dy).sum()
+        tot.backward()
+        tag = name + ('_ds' if ds else '')
+        data[tag + '_y'] = np.stack([o.detach().numpy() for o in outs])[..., ::2, ::2].copy()     # every 2nd pixel: keeps the file small
+        data[tag + '_dx'] = xr.grad.numpy()[..., ::2, ::2].copy()
+        data[tag + '_gd'] = param_digests(m, True)
+        print(tag, data[tag + '_y'].shape)
+    np.savez_compressed(os.path.join(OUT, 'archs.npz'), **data)
+
+
 def gen_unwired(mods):
     """Golden vectors for the named-but-unwired blocks, from the
     reference's own batchnorm.py, archs.up_conv, xresidualblock.py, spectral_norm.py and
@@ -332,6 +361,8 @@ def main():
         gen_unwired(mods)
     if a.only in (None, 'stage1'):
         gen_stage1(mods)
+    if a.only in (None, 'archs'):
+        gen_archs(mods)
     if a.only in (None, 'step64'):
         gen_step(mods, 'step_n2_64', 2, 64, 64, steps=2)
     if a.only in (None, 'step256'):

@@ -87,6 +87,7 @@ SIGNATURES = {
     'ssg_spade_modulate_bwd_f32': [_P, _I, _P, _I, _P, _I, _L, _I, _P, _I, _P, _I, _P],
     'ssg_act_bwd_f32': [_P, _I, _P, _I, _L, _I, _I, _F, _P, _I, _P],
     'ssg_add_f32': [_P, _P, _L, _P, _P],
+    'ssg_copy_channels_f32': [_P, _I, _L, _I, _P, _I, _P],
     'ssg_nan_to_zero_f32': [_P, _L, _P, _P],
     'ssg_mask_zero_f32': [_P, _P, _L, _P, _P],
     'ssg_seg_loss_workspace_bytes': [_I, _L, _I],

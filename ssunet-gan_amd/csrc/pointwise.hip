@@ -124,6 +124,15 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(const void* const* __re
   }
 }
 
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, int lds_, long long P, int C,
+                                                            float* __restrict__ dst, int ldd) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, P * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    *(f32x4*)(dst + p * ldd + 4 * cq) = *(const f32x4*)(src + p * lds_ + 4 * cq);
+  }
+}
+
 __global__ __launch_bounds__(256) void clamp_multi_kernel(const void* const* __restrict__ ptrs, const long long* __restrict__ sizes,
                                                           const int* __restrict__ blk_tensor, const int* __restrict__ blk_chunk, int stride,
                                                           float lo, float hi) {
@@ -201,6 +210,15 @@ extern "C" int ssg_clamp_multi_f32(const void* const* ptrs, const int64_t* sizes
   SSG_REQUIRE(ptrs && sizes && blk_tensor && blk_chunk && nblocks > 0 && which >= 0 && which < 4, SSG_EINVAL, "clamp_multi: bad args");
   hipLaunchKernelGGL(clamp_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const void* const*)(ptrs + which),
                      (const long long*)sizes, blk_tensor, blk_chunk, 4, lo, hi);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+/* dst[p, 0:C] = src[p, 0:C] for P pixels (channel-slice copy: materialises torch.cat of more than two
+ * tensors, e.g. the dense skip connections of NestedUNet, archs.py:910-925). */
+extern "C" int ssg_copy_channels_f32(const float* src, int ldsrc, int64_t P, int C, float* dst, int lddst, void* stream) {
+  SSG_REQUIRE(src && dst && P > 0 && C > 0 && C % 4 == 0 && ldsrc % 4 == 0 && lddst % 4 == 0, SSG_EINVAL, "copy_channels: bad args");
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, ldsrc, (long long)P, C, dst, lddst);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -1049,3 +1049,35 @@ def add(a, b):
     """a + b for two NHWC tensors of the same shape."""
     _lib.require_gpu(a)
     return _Add.apply(a, b)
+
+
+class _ConcatChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [to_nhwc(x) for x in xs]
+        n, _, h, w = xs[0].shape
+        cs = [x.shape[1] for x in xs]
+        if any(c % 4 for c in cs):
+            raise ValueError('concat_channels: every input needs C %% 4 == 0 (got %s)' % cs)
+        y = new_nhwc(n, sum(cs), h, w, xs[0].device)
+        off = 0
+        for x, c in zip(xs, cs):
+            dst = y[:, off:off + c]
+            call('ssg_copy_channels_f32', ptr(x), _ld(x), n * h * w, c, ptr(dst), _ld(y), stream_ptr())
+            off += c
+        ctx.cs = cs
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for c in ctx.cs:
+            outs.append(g[:, off:off + c])
+            off += c
+        return tuple(outs)
+
+
+def concat_channels(*xs):
+    """torch.cat(xs, 1) materialised (only needed for more than two inputs; convs take two pointers)."""
+    _lib.require_gpu(xs[0])
+    return xs[0] if len(xs) == 1 else _ConcatChannels.apply(*xs)
