@@ -262,6 +262,38 @@ def gen_archs(mods):
     np.savez_compressed(os.path.join(OUT, 'archs.npz'), **data)
 
 
+def gen_infer(mods):
+    """Eval-mode generator as the sliding-window API drives it (aerial_image_segmentation_api.py:376-390):
+    one train-mode forward to give the batch norms non-trivial running statistics, then model.eval(),
+    one patch per forward, sigmoid.  Also the patch order of patch_gen on a small image."""
+    archs = mods[0]
+    torch.manual_seed(41)
+    model = archs.UNet_R_SS_v2(3, 3, False)
+    model.train()
+    inp, _ = synthetic_batch(2, 64, 64)
+    with torch.no_grad():
+        model(inp)
+    model.eval()
+    g = torch.Generator().manual_seed(61)
+    patches = torch.rand(5, 3, 64, 64, generator=g)
+    outs = []
+    with torch.no_grad():
+        for p_ in patches:
+            outs.append(torch.sigmoid(model(p_.unsqueeze(0)))[0].numpy())
+    # patch_gen order: needs cv2-free import of the function only -> restate the call through the module source
+    import importlib.util, types as _t
+    src = open(os.path.join(REF, 'aerial_image_segmentation_api.py')).read()
+    start = src.index('def patch_gen('); end = src.index('def patch_merge(')
+    ns = {'math': __import__('math')}
+    exec(compile(src[start:end], 'patch_gen_extract', 'exec'), ns)         # runs the reference's own function text in memory
+    img = np.arange(40 * 56 * 1).reshape(40, 56, 1)
+    ip, _ = ns['patch_gen'](img, img, 16, 0.5)
+    origins = np.array([[int(p_[0, 0, 0]) // 56, int(p_[0, 0, 0]) % 56] for p_ in ip])
+    np.savez_compressed(os.path.join(OUT, 'infer.npz'), patches=patches.numpy(), probs=np.stack(outs), origins=origins,
+                        img_hw=np.array([40, 56]), p_size=np.array(16))
+    print('infer.npz', np.stack(outs).shape, origins.shape)
+
+
 def gen_unwired(mods):
     """Golden vectors for the named-but-unwired blocks, from the
     reference's own batchnorm.py, archs.up_conv, xresidualblock.py, spectral_norm.py and
@@ -363,6 +395,8 @@ def main():
         gen_stage1(mods)
     if a.only in (None, 'archs'):
         gen_archs(mods)
+    if a.only in (None, 'infer'):
+        gen_infer(mods)
     if a.only in (None, 'step64'):
         gen_step(mods, 'step_n2_64', 2, 64, 64, steps=2)
     if a.only in (None, 'step256'):

@@ -43,12 +43,31 @@ class BasicBlock(nn.Module):
         sc = self.shortcut[0] if len(self.shortcut) else None
         if self.training:
             return basic_block(x, x2, self.conv1, self.bn1, self.conv2, self.bn2, sc, group=_sync_group(self.bn1))
+        # eval mode: the running-stat batch norms are folded into the conv weights, so the block is three
+        # MFMA launches with bias / residual / ReLU epilogues and no batch-norm pass (sliding-window
+        # inference, aerial_image_segmentation_api.py:376-390)
         s = self.conv1.stride[0]
-        y = ops.conv2d(x, self.conv1.weight, None, s, 1, x2=x2)
-        y = ops.batch_norm_act(y, self.bn1, act=ACT_RELU)
-        y = ops.conv2d(y, self.conv2.weight, None, 1, 1)
+        w1, b1, w2, b2 = self._folded()
+        y = ops.conv2d(x, w1, b1, s, 1, act=ACT_RELU, x2=x2)
         r = ops.conv2d(x, sc.weight, None, s, 0, x2=x2) if sc is not None else x
-        return ops.batch_norm_act(y, self.bn2, res=r, act=ACT_RELU)
+        return ops.conv2d(y, w2, b2, 1, 1, act=ACT_RELU, res=r)
+
+    def _folded(self):
+        """(w1', b1', w2', b2') with w' = w * gamma/sqrt(var+eps), b' = beta - mean*gamma/sqrt(var+eps);
+        cached until a parameter or running statistic changes."""
+        srcs = (self.conv1.weight, self.conv2.weight, self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var,
+                self.bn2.weight, self.bn2.bias, self.bn2.running_mean, self.bn2.running_var)
+        stamp = tuple((t.data_ptr(), t._version) for t in srcs) + (ops._WEIGHT_EPOCH[0],)
+        hit = getattr(self, '_fold_cache', None)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        with torch.no_grad():
+            out = []
+            for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2)):
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                out += [(conv.weight * scale.view(-1, 1, 1, 1)).contiguous(), (bn.bias - bn.running_mean * scale).contiguous()]
+        self._fold_cache = (stamp, tuple(out))
+        return self._fold_cache[1]
 
 
 def _cat_split(xs):

@@ -344,13 +344,15 @@ class _Conv2d(torch.autograd.Function):
     """F.conv2d (+bias, +activation, optional second input = channel concat) on MFMA."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, stride, pad, act, slope):
+    def forward(ctx, x1, x2, weight, bias, stride, pad, act, slope, res=None):
         x1 = to_nhwc(x1)
         x2 = to_nhwc(x2) if x2 is not None else None
-        y = _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope)
+        res = to_nhwc(res) if res is not None else None
+        y = _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=res)
         ctx.cfg = (stride, pad, act, slope)
         ctx.save_for_backward(x1, x2, weight, y if act != ACT_NONE else None)
         ctx.has_bias = bias is not None
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -371,15 +373,17 @@ class _Conv2d(torch.autograd.Function):
             dw = _conv_wgrad_impl(x1, x2, dy, weight.shape, stride, pad)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = _channel_sum(dy, weight.shape[0])
-        return dx1, dx2, dw, db, None, None, None, None
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[8]) else None      # residual joins before the activation
+        return dx1, dx2, dw, db, None, None, None, None, dres
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, x2=None):
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, x2=None, res=None):
     """F.conv2d on the HIP kernels.  `padding`: int or (top, bottom, left, right) (TF-"same" static
-    padding of the EfficientNet convs is asymmetric); `x2`: second tensor concatenated after x."""
+    padding of the EfficientNet convs is asymmetric); `x2`: second tensor concatenated after x;
+    `res`: tensor added in the epilogue before the activation (act(conv(x) + bias + res))."""
     _lib.require_gpu(x)
     pad = tuple(int(v) for v in padding) if isinstance(padding, (tuple, list)) else int(padding)
-    return _Conv2d.apply(x, x2, weight, bias, int(stride), pad, int(act), float(slope))
+    return _Conv2d.apply(x, x2, weight, bias, int(stride), pad, int(act), float(slope), res)
 
 
 # ----------------------------------------------------------------------------- linear (as 1x1 conv over a 1 x N "image")
