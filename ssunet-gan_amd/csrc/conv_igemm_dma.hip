@@ -18,6 +18,10 @@
 #include "common.h"
 #include "conv_args.h"
 
+#ifndef SSG_EXPERIMENT
+#define SSG_EXPERIMENT 0
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(64))) float ssg_zero_page[64];
@@ -29,7 +33,11 @@ __device__ __forceinline__ void dma16(const float* src, float* lds_dst) {
   __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
 }
 
-constexpr int NSTAGE = 3;
+#ifndef SSG_DMA_STAGES
+#define SSG_DMA_STAGES 3
+#endif
+constexpr int NSTAGE = SSG_DMA_STAGES;      // LDS stages; NSTAGE-1 K-steps are in flight across each barrier
+constexpr int AHEAD = NSTAGE - 1;
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
@@ -85,6 +93,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
     const int c0 = chunk * 16;
     const float* src; int ld, cc;
     if (c0 < a.C1) { src = a.in1; ld = a.ld1; cc = c0; } else { src = a.in2; ld = a.ld2; cc = c0 - a.C1; }
+#if SSG_EXPERIMENT != 3
 #pragma unroll
     for (int j = 0; j < A_PC; ++j) {
       const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
@@ -92,11 +101,14 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
       const float* p = ok ? src + ((size_t)(n * a.H + iy) * a.W + ix) * ld + cc + a_q[j] : zero;
       dma16(p, st + (wave * A_PC + j) * 256);
     }
+#endif
+#if SSG_EXPERIMENT != 4
 #pragma unroll
     for (int j = 0; j < B_PC; ++j) {
       const float* p = b_src[j] ? b_src[j] + (size_t)s * 16 : zero;
       dma16(p, st + BM * 16 + (wave * B_PC + j) * 256);
     }
+#endif
   };
 
   f32x16 acc[MI][NI];
@@ -113,15 +125,23 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
   const int qoff0 = 4 * ((0 + half) ^ sw), qoff1 = 4 * ((2 + half) ^ sw);
 
   const int nsteps = a.nsteps;
-  issue(0);
-  if (nsteps > 1) issue(1);
+#pragma unroll
+  for (int p = 0; p < AHEAD; ++p)
+    if (p < nsteps) issue(p);
 
   for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PC + B_PC) : "memory");
+    // steps s+1 .. s+AHEAD-1 may stay in flight; near the tail fewer are outstanding
+    const int rem = nsteps - 1 - s;
+#if SSG_EXPERIMENT == 3 || SSG_EXPERIMENT == 4
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (false)
+#endif
+    if (rem >= AHEAD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * (A_PC + B_PC)) : "memory");
+    else if (AHEAD >= 3 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PC + B_PC) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (s + 2 < nsteps) issue(s + 2);
+    if (s + AHEAD < nsteps) issue(s + AHEAD);
     const float* st = lds + (s % NSTAGE) * STAGE;
     const float* Ab = st + (wm * WTM + l31) * 16;
     const float* Bb = st + BM * 16 + (wn * WTN + l31) * 16;

@@ -307,14 +307,15 @@ bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // Which thin kernels are enabled: bit0 = T1 small-Cout conv, bit1 = T2 small-Cin conv, bit2 = T3
 // wgrad (dout thin), bit3 = T4 wgrad (in thin).  Round-1 measurements at 16x512^2 (ms per launch,
 // thin vs MFMA path): T1 0.93 vs 1.85 (64->4); T2 0.99 vs 0.92 (3->64), 0.83 vs 0.58 (4->64);
-// T3 4.0 vs 2.6 (64->3); T4 1.63 vs 1.0 (3->64).  Only T1 wins, and it is worth ~2 % of the step,
-// so ALL are off by default in round 1 (one conv path to reason about for parity); they are
-// opt-in through SSG_THIN_MASK and kept exact by tests/test_ops_gpu.py (which enables all four).
+// T3 4.0 vs 2.6 (64->3); T4 1.63 vs 1.0 (3->64).  Only T1 wins (and is ~6x closer to an fp64
+// reference than the MFMA path: 16-lane partial sums + a shuffle tree instead of one long fmaf
+// chain), so T1 is ON by default and T2-T4 are opt-in through SSG_THIN_MASK; all four are kept
+// exact by tests/test_ops_gpu.py (which enables them in a subprocess).
 int thin_mask() {
   static int m = -1;
   if (m < 0) {
     const char* e = getenv("SSG_THIN_MASK");
-    m = e ? atoi(e) : 0;
+    m = e ? atoi(e) : 1;
   }
   return m;
 }
