@@ -70,7 +70,7 @@ def basic_block(x1, x2, conv1, bn1, conv2, bn2, shortcut_conv, group=None):
     for bn in (bn1, bn2):
         if bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
-    var_mode = 1 if group is not None else 0
+    var_mode = getattr(bn1, '_ssg_var_mode', 1 if group is not None else 0)
     return _BasicBlockFn.apply(x1, x2, conv1.weight, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
                                conv2.weight, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
                                shortcut_conv.weight if shortcut_conv is not None else None,

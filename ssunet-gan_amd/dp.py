@@ -39,7 +39,8 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # RCCL ('nccl') on GPUs; SSG_DIST_BACKEND=gloo lets several ranks share one GPU in rehearsals
+            backend = os.environ.get('SSG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         kw = {}
         if backend == 'nccl':
             kw['device_id'] = torch.device('cuda', torch.cuda.current_device())

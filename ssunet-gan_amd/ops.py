@@ -539,7 +539,7 @@ def batch_norm_act(x, bn, res=None, act=ACT_NONE, slope=0.0, group=None, var_mod
         if bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         if var_mode is None:
-            var_mode = 1 if group is not None else 0
+            var_mode = getattr(bn, '_ssg_var_mode', 1 if group is not None else 0)
         return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                                    bn.running_var if bn.track_running_stats else None, res, float(bn.eps), float(bn.momentum),
                                    int(act), float(slope), int(var_mode), group)
