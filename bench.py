@@ -26,6 +26,31 @@ import torch.nn as nn
 
 FLOP_PER_IMG_512 = 1.6951e12        # 2*(3*208.625 + 9*24.631) GFLOP per image per step
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+# separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950):
+# profiles/r01_c_pmc_hbm_traffic_per_kernel.csv.  Static: bench.py cannot run the profiler on itself.
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {'conv_igemm_dma_kernel<128,128>': 568813859, 'wgrad_dma_kernel<128,128>': 2000343242,
+                                'conv_igemm_dma_kernel<256,64>': 1458381807}
+
+
+def measured_ceilings(S, dev):
+    """fp32-MFMA issue peak and HBM copy rate of THIS device (csrc/tools.hip), to read the fractions against."""
+    from ssunet_gan_amd._lib import call, ptr, stream_ptr
+    scratch = torch.empty(768 * 256, device=dev)
+    def timeit(fn, n):
+        fn(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    it = 2000
+    ms = timeit(lambda: call('ssg_tool_mfma_peak_f32', ptr(scratch), 768, it, stream_ptr()), 3)
+    mfma = 768 * 4 * it * 16 * 4096 / ms / 1e9
+    a = torch.empty(1 << 27, device=dev); b = torch.empty(1 << 27, device=dev)
+    ms = timeit(lambda: call('ssg_tool_copy_f32', ptr(a), ptr(b), a.numel(), stream_ptr()), 3)
+    return {'mfma_f32_tflops': round(mfma, 1), 'hbm_copy_tbps': round(2 * a.numel() * 4 / ms / 1e9, 2)}
 
 
 def host_cores():
@@ -151,7 +176,8 @@ def main():
             label, (fl, tt, cnt) = dom
             ach = fl / tt / 1e12
             roof = {'bound': 'mfma', 'kernel': label, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'traffic': PMC_TRAFFIC_BYTES_PER_LAUNCH.get(label),
                     'launches': cnt, 'avg_launch_ms': round(tt / cnt * 1e3, 4),
                     'all_mfma_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'time_frac_of_step': round(v[1] / dt, 4),
                                              'launches': v[2]} for k, v in sorted(agg.items())},
@@ -168,6 +194,8 @@ def main():
             'loss': round(float(out[0]), 6), 'iou': round(float(out[1]), 6), 'dice': round(float(out[2]), 6),
             'roofline': roof,
         }
+        if world == 1:
+            line['measured_ceilings'] = measured_ceilings(S, dev)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line))

@@ -169,6 +169,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       if (dbias) dbias[c] = (float)sums[c];
     }
   }
+  // per-channel fp64 constants once per block (the fp64 divisions are not repeated per element)
+  extern __shared__ double kc[];                 // [4][C]: mean, invstd, w*invstd, then m1 | m2 packed below
+  double* k_mean = kc; double* k_is = kc + C; double* k_ws = kc + 2 * C; double* k_m1 = kc + 3 * C; double* k_m2 = kc + 4 * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double is = (double)invstd[c];
+    k_mean[c] = (double)mean[c]; k_is[c] = is; k_ws[c] = (weight ? (double)weight[c] : 1.0) * is;
+    k_m1[c] = sums[c] / count; k_m2[c] = sums[C + c] / count;
+  }
+  __syncthreads();
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long p = i / CQ; const int cq = (int)(i - p * CQ);
     f32x4 g = *(const f32x4*)(dy + p * lddy + 4 * cq);
@@ -188,11 +197,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int c = 4 * cq + e;
-        const double is = (double)invstd[c];
-        const double xh = ((double)xv[e] - (double)mean[c]) * is;
-        const double m1 = sums[c] / count, m2 = sums[C + c] / count;
-        const double w = weight ? (double)weight[c] : 1.0;
-        o[e] = (float)((w * is) * ((double)g[e] - m1 - xh * m2));
+        const double xh = ((double)xv[e] - k_mean[c]) * k_is[c];
+        o[e] = (float)(k_ws[c] * ((double)g[e] - k_m1[c] - xh * k_m2[c]));
       }
       *(f32x4*)(dx + p * lddx + 4 * cq) = o;
     }
@@ -276,7 +282,12 @@ extern "C" int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float*
   SSG_REQUIRE(x && dy && mean && invstd && sums && P > 0 && C > 0 && count > 0, SSG_EINVAL, "bn_bwd_apply: bad args");
   SSG_REQUIRE(act == SSG_ACT_NONE || y, SSG_EINVAL, "bn_bwd_apply: activation mask needs y");
   SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_apply: alignment");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, dy,
+  SSG_REQUIRE(C <= 4096, SSG_EINVAL, "bn_bwd_apply: C > 4096");
+  if ((size_t)5 * C * sizeof(double) > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)bn_bwd_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * C * (int)sizeof(double));
+    if (e != hipSuccess) { ssg_set_error("bn_bwd_apply: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), (size_t)5 * C * sizeof(double), (hipStream_t)stream, x, y, dy,
                      P, C, ldx, ldy, lddy, mean, invstd, weight, sums, count, act, slope, dx, lddx, dres, lddres, dweight,
                      dbias);
   SSG_LAUNCH_CHECK();
