@@ -147,22 +147,23 @@ struct RedArgs {
   int ky[SSG_MAX_TAPS], kx[SSG_MAX_TAPS];
 };
 
-// 32 gradient elements x 8 split-lanes per block: lane z adds slabs z, z+8, ... in order, then the
-// 8 lane sums are added in lane order -> fixed summation order, short serial chains.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
-  __shared__ float red[8][32];
+// 32 gradient elements x ZL split-lanes per block: lane z adds slabs z, z+ZL, ... in order, then the
+// ZL lane sums are added in lane order -> fixed summation order, short serial chains.
+template <int ZL>
+__global__ __launch_bounds__(32 * ZL) void wgrad_reduce_kernel(const RedArgs a) {
+  __shared__ float red[ZL][32];
   const int el = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const long long idx = (long long)blockIdx.x * 32 + el;
   const long long tot = (long long)a.M * a.Cout;
   float s = 0.f;
   if (idx < tot)
-    for (int z = zl; z < a.splits; z += 8) s += a.ws[(size_t)z * tot + idx];
+    for (int z = zl; z < a.splits; z += ZL) s += a.ws[(size_t)z * tot + idx];
   red[zl][el] = s;
   __syncthreads();
   if (zl != 0 || idx >= tot) return;
   float v = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v += red[k][el];
+  for (int k = 0; k < ZL; ++k) v += red[k][el];
   const int row = (int)(idx / a.Cout), co = (int)(idx - (long long)row * a.Cout);
   const int t = row / a.Cin, c = row - t * a.Cin;
   if (c >= a.Cin_real) return;
@@ -170,6 +171,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
 }
 
 struct Plan { int variant, mt, nt, splits, steps_per_split; };
+
+// thin weight gradients on the 4x4x1 MFMA (conv_wgrad4.hip); SSG_WGRAD4=0 switches them off (A/B)
+int wgrad4_kind(const ssg_wgrad_desc* d) {
+  static const int on = [] { const char* e = getenv("SSG_WGRAD4"); return e ? atoi(e) : 1; }();
+  return on ? ssg_wgrad4_kind(d) : 0;
+}
 
 bool wgrad_uses_dma(int variant) {
   static const int use_dma = [] { const char* e = getenv("SSG_WGRAD_DMA"); return e ? atoi(e) : 1; }();
@@ -244,6 +251,10 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 
 extern "C" int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d) {
   if (!d) return 0;
+  if (wgrad4_kind(d)) {
+    const int nz = ssg_wgrad4_slices(d, wgrad4_kind(d), nullptr, nullptr, nullptr);
+    return (int64_t)nz * d->ntaps * (d->C1 + d->C2) * d->Cout * (int64_t)sizeof(float);
+  }
   if (ssg_thin_wgrad_kind(d)) {
     const int splits = ssg_thin_wgrad_splits(d, nullptr);
     return (int64_t)splits * d->ntaps * (d->C1 + d->C2) * d->Cout * (int64_t)sizeof(float);
@@ -257,7 +268,8 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   if (rc != SSG_OK) return rc;
   Plan p = make_plan(d);
   hipStream_t st = (hipStream_t)stream;
-  const int thin = ssg_thin_wgrad_kind(d);
+  const int w4 = wgrad4_kind(d);
+  const int thin = w4 ? 0 : ssg_thin_wgrad_kind(d);
   WgArgs a;
   a.in1 = d->in1; a.in2 = d->C2 ? d->in2 : d->in1; a.dout = d->dout; a.ws = d->ws;
   a.C1 = d->C1; a.C2 = d->C2; a.ld1 = d->ld1; a.ld2 = d->C2 ? d->ld2 : d->ld1;
@@ -269,7 +281,11 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   a.M = d->ntaps * (d->C1 + d->C2);
   a.Ptot = (long long)d->N * d->GH * d->GW;
   a.steps_per_split = p.steps_per_split;
-  if (thin) {
+  if (w4) {
+    p.splits = ssg_wgrad4_slices(d, w4, nullptr, nullptr, nullptr);
+    rc = ssg_wgrad4_launch(d, w4, st);
+    if (rc != SSG_OK) return rc;
+  } else if (thin) {
     p.splits = ssg_thin_wgrad_splits(d, nullptr);
     rc = ssg_thin_wgrad_launch(d, thin, st);
     if (rc != SSG_OK) return rc;
@@ -291,7 +307,11 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   r.Cin_real = d->Cin_real; r.KH = d->KH; r.KW = d->KW; r.ntaps = d->ntaps;
   for (int t = 0; t < SSG_MAX_TAPS; ++t) { r.ky[t] = t < d->ntaps ? d->ky[t] : 0; r.kx[t] = t < d->ntaps ? d->kx[t] : 0; }
   const long long tot = (long long)a.M * d->Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ssg_cdiv(tot, 32)), dim3(256), 0, st, r);
+  // many slabs over few elements (the thin layers): 32 split-lanes keep the serial chains short
+  if (p.splits >= 256 && tot <= 32 * 1024)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3((unsigned)ssg_cdiv(tot, 32)), dim3(1024), 0, st, r);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)ssg_cdiv(tot, 32)), dim3(256), 0, st, r);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -319,9 +339,10 @@ extern "C" int ssg_pack_weights_f32(const float* w_oihw, int O, int I, int KH, i
   return SSG_OK;
 }
 
-// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 13/14 = thin
+// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 13/14 = thin (VALU), 15/16 = wgrad4 (4x4x1 MFMA)
 extern "C" int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d) {
   if (!d) return SSG_EINVAL;
+  if (wgrad4_kind(d)) return 10 + wgrad4_kind(d);
   const int k = ssg_thin_wgrad_kind(d);
   if (k) return 10 + k;
   const int v = make_plan(d).variant;

@@ -1,0 +1,171 @@
+// Weight gradients of "thin" convolutions on v_mfma_f32_4x4x1_16B_f32 (gfx950).
+//
+// When one side of a conv has <= 4 channels (SPADE's C->3 / 3->h / h->C chain, the 3-channel image,
+// logit and mask layers) a 32x32 MFMA tile pads the thin side 8-10x.  The 4x4x1 MFMA computes 16
+// independent 4x4 outer products per instruction at the same FLOP rate, which is exactly this shape:
+//     D_b[i][j] += A[4b+i] * B[4b+j]      (b = 0..15; measured on gfx950: D_b[i][j] sits in lane 4b+j, reg i)
+//   thin-Cout (dout has <= 4 channels, in has C): A = in[p + tap][c0 + lane], B = dout[p][lane % 4]
+//        -> lane 4b+j, reg i holds dw[co = j][tap][c = c0 + 4b + i]
+//   thin-Cin  (in has 4 channels, dout has Cout): A = dout[p][co0 + lane],    B = in[p + tap][lane % 4]
+//        -> lane 4b+j, reg i holds dw[co = co0 + 4b + i][tap][c = j]
+// One wave owns a 64-channel group of the wide tensor and all taps (9 accumulators x 4 registers),
+// streams pixels with whole 256-B rows per load, and ends with one slab write; slabs are summed by the
+// ordered reducer of conv_wgrad.hip (bitwise reproducible, no atomics).  HBM-bound by construction.
+#include "common.h"
+#include "conv_thin.h"
+
+namespace {
+
+struct W4Args {
+  const float* wide; const float* thin; float* ws;
+  int Cw, ldw, ldt, N, H, W, Cout, Cin;
+  int groups, nz;            // 64-channel groups of the wide tensor; slabs (= workgroups per group)
+  long long units_per_z;     // row segments per slice
+  int segs_per_row;
+};
+
+constexpr int SEG = 32;      // pixels per work unit (one row segment)
+constexpr int U = 8;         // pixels per inner step: (U+KS-1)*KS + U loads, then U*KS*KS MFMAs
+
+// KS = 3: taps t = (dy+1)*3 + (dx+1), pad 1;  KS = 1: the single tap (0,0).
+template <bool THIN_COUT, int KS>
+__global__ __launch_bounds__(256) void wgrad4_kernel(const W4Args a) {
+  constexpr int R = KS / 2, NT = KS * KS, COLS = U + KS - 1;
+  const int lane = threadIdx.x & 63;
+  // the 4 waves of a workgroup share the channel group and own 4 consecutive pixel slices; their
+  // accumulators are summed through LDS in wave order, so one workgroup writes one slab
+  const int wave = threadIdx.x >> 6;
+  const int zb = blockIdx.x / a.groups, cg = blockIdx.x - zb * a.groups;
+  const int z = zb * 4 + wave;
+  const int j = lane & 3;
+  const int cw = cg * 64 + lane;                 // this lane's channel of the wide tensor
+  const bool cw_ok = cw < a.Cw;
+  // the tap-shifted tensor ("in") and the fixed one ("dout") are read through buffer descriptors: an
+  // out-of-image tap / padded lane gets byte offset 0xffffffff, which the range check turns into 0.0f --
+  // no branches, no selects (tensors are < 4 GiB, checked on the host)
+  const float* tapT = THIN_COUT ? a.wide : a.thin;
+  const float* fixT = THIN_COUT ? a.thin : a.wide;
+  const unsigned ldtap = THIN_COUT ? a.ldw : a.ldt, ldfix = THIN_COUT ? a.ldt : a.ldw;
+  const unsigned npix = (unsigned)(a.N * a.H * a.W);
+  const auto tap_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tapT), 0, (int)(npix * ldtap * 4u), 0x00020000);
+  const auto fix_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fixT), 0, (int)(npix * ldfix * 4u), 0x00020000);
+  const unsigned chtap = THIN_COUT ? cw : j, chfix = THIN_COUT ? j : cw;
+  const bool tap_lane_ok = THIN_COUT ? cw_ok : true, fix_lane_ok = THIN_COUT ? true : cw_ok;
+  constexpr unsigned OOB = 0xffffffffu;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int u0 = z * (int)a.units_per_z;
+  const int total_units = a.N * a.H * a.segs_per_row;
+  int u1 = u0 + (int)a.units_per_z; if (u1 > total_units) u1 = total_units;
+  for (int u = u0; u < u1; ++u) {
+    const int r = u / a.segs_per_row; const int seg = u - r * a.segs_per_row;
+    const int y = r % a.H, n = r / a.H;
+    const int x0 = seg * SEG;
+    const int x1 = x0 + SEG < a.W ? x0 + SEG : a.W;
+    unsigned rowoff[KS]; bool rowok[KS];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int iy = y + q - R;
+      rowok[q] = tap_lane_ok && (unsigned)iy < (unsigned)a.H;
+      rowoff[q] = ((unsigned)((n * a.H + iy) * a.W) * ldtap + chtap) * 4u;
+    }
+    const unsigned fixoff = ((unsigned)((n * a.H + y) * a.W) * ldfix + chfix) * 4u;
+    for (int xb = x0; xb < x1; xb += U) {
+      float f[U], v[KS][COLS];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const bool ok = fix_lane_ok && (xb + k < x1);
+        f[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            fix_rs, ok ? fixoff + (unsigned)(xb + k) * ldfix * 4u : OOB, 0, 0));
+      }
+#pragma unroll
+      for (int c = 0; c < COLS; ++c) {
+        const int ix = xb + c - R;
+        const bool cok = (unsigned)ix < (unsigned)a.W;
+        const unsigned xo = (unsigned)ix * ldtap * 4u;
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+          v[q][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+              tap_rs, (cok && rowok[q]) ? rowoff[q] + xo : OOB, 0, 0));
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k)
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+#pragma unroll
+          for (int e = 0; e < KS; ++e) {
+            if (THIN_COUT) acc[q * KS + e] = __builtin_amdgcn_mfma_f32_4x4x1f32(v[q][k + e], f[k], acc[q * KS + e], 0, 0, 0);
+            else acc[q * KS + e] = __builtin_amdgcn_mfma_f32_4x4x1f32(f[k], v[q][k + e], acc[q * KS + e], 0, 0, 0);
+          }
+    }
+  }
+  __shared__ float red[4][NT * 4][64];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][t * 4 + i][lane] = acc[t][i];
+  __syncthreads();
+  // slab layout of conv_wgrad.hip: [slab][row = t*Cin + c][Cout]
+  float* slab = a.ws + (size_t)zb * NT * a.Cin * a.Cout;
+  const int b4 = (lane >> 2) * 4;
+  for (int e = wave; e < NT * 4; e += 4) {
+    const int t = e >> 2, i = e & 3;
+    const float sum = ((red[0][e][lane] + red[1][e][lane]) + red[2][e][lane]) + red[3][e][lane];
+    int co, c;
+    if (THIN_COUT) { co = j; c = cg * 64 + b4 + i; }
+    else { co = cg * 64 + b4 + i; c = j; }
+    if (co < a.Cout && c < a.Cin) slab[((size_t)t * a.Cin + c) * a.Cout + co] = sum;
+  }
+}
+
+}  // namespace
+
+// kind 5: dout thin (Cout <= 4), kind 6: in thin (Cin_pad == 4)
+int ssg_wgrad4_kind(const ssg_wgrad_desc* d) {
+  if (d->C2 != 0 || d->in_sy != 1 || d->in_sx != 1 || d->GH != d->H || d->GW != d->W) return 0;
+  if (d->ntaps == 9) {
+    for (int t = 0; t < 9; ++t) if (d->dy[t] != t / 3 - 1 || d->dx[t] != t % 3 - 1) return 0;
+  } else if (d->ntaps != 1 || d->dy[0] != 0 || d->dx[0] != 0) {
+    return 0;
+  }
+  // 32-bit byte offsets (buffer descriptors) inside the kernel
+  if ((long long)d->N * d->H * d->W * (d->ld1 > d->ldd ? d->ld1 : d->ldd) >= (1ll << 30)) return 0;
+  if (d->Cout <= 4 && d->C1 >= 16 && d->C1 % 4 == 0) return 5;
+  if (d->C1 == 4) return 6;
+  return 0;
+}
+
+int ssg_wgrad4_slices(const ssg_wgrad_desc* d, int kind, int* groups, long long* units_per_z, int* segs_per_row) {
+  const int cw = kind == 5 ? d->C1 : d->Cout;
+  const int g = (cw + 63) / 64;
+  const int spr = (d->W + SEG - 1) / SEG;
+  const long long units = (long long)d->N * d->H * spr;
+  long long nz = 8192 / g;                       // ~32 waves per CU in total
+  if (nz > units) nz = units;
+  if (nz < 1) nz = 1;
+  const long long upz = (units + nz - 1) / nz;
+  nz = (units + upz - 1) / upz;
+  nz = (nz + 3) / 4;                             // slabs = workgroups per channel group (4 slices each)
+  if (groups) *groups = g;
+  if (units_per_z) *units_per_z = upz;
+  if (segs_per_row) *segs_per_row = spr;
+  return (int)nz;
+}
+
+int ssg_wgrad4_launch(const ssg_wgrad_desc* d, int kind, hipStream_t st) {
+  W4Args a;
+  a.ws = d->ws; a.N = d->N; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Cin = d->C1;
+  a.nz = ssg_wgrad4_slices(d, kind, &a.groups, &a.units_per_z, &a.segs_per_row);
+  const dim3 grid((unsigned)(a.nz * a.groups)), block(256);
+  if (kind == 5) { a.wide = d->in1; a.Cw = d->C1; a.ldw = d->ld1; a.thin = d->dout; a.ldt = d->ldd; }
+  else { a.wide = d->dout; a.Cw = d->Cout; a.ldw = d->ldd; a.thin = d->in1; a.ldt = d->ld1; }
+  if (kind == 5 && d->ntaps == 9) hipLaunchKernelGGL((wgrad4_kernel<true, 3>), grid, block, 0, st, a);
+  else if (kind == 5) hipLaunchKernelGGL((wgrad4_kernel<true, 1>), grid, block, 0, st, a);
+  else if (d->ntaps == 9) hipLaunchKernelGGL((wgrad4_kernel<false, 3>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((wgrad4_kernel<false, 1>), grid, block, 0, st, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
