@@ -325,9 +325,11 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
 // Dispatcher: thin VALU kernels for the <= 8-channel cases, MFMA implicit GEMM otherwise.
 // ssg_conv2d_kernel_id reports which kernel a descriptor maps to (for profiling labels):
 //   0..2 = conv_igemm<128,128> / <256,64> / <256,32>, 20/21 = conv_igemm_dma<128,128> / <256,64>,
-//   10 = thin small-Cout, 11 = thin small-Cin.
+//   12 = thin4 (4x4x1 MFMA) 4-channel input, 13 = thin4 Cout <= 4, 10 = thin small-Cout (VALU), 11 = thin small-Cin (VALU).
 extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
   if (!d) return SSG_EINVAL;
+  const int k4 = ssg_thin4_conv_kind(d);
+  if (k4) return 9 + k4;
   const int k = ssg_thin_conv_kind(d);
   if (k) return 9 + k;
   return pick_variant(d) + (uses_dma(d) ? 20 : 0);
@@ -336,6 +338,8 @@ extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
 extern "C" int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc != SSG_OK) return rc;
+  const int k4 = ssg_thin4_conv_kind(d);
+  if (k4) return ssg_thin4_conv_launch(d, k4, (hipStream_t)stream);
   const int k = ssg_thin_conv_kind(d);
   if (k) return ssg_thin_conv_launch(d, k, (hipStream_t)stream);
   return ssg_conv2d_igemm_f32(d, stream);

@@ -1,0 +1,322 @@
+// Thin convolutions (one side <= 4 channels) on v_mfma_f32_4x4x1_16B_f32 (gfx950).
+//
+//   D_b[i][j] += A[4b+i] * B[4b+j]   (16 independent 4x4 blocks b; D_b[i][j] sits in lane 4b+j, register i)
+//
+// thin-Cin  (in has 4 channels, any Cout):  A = w[co = co0 + lane][tap][c]  (36 registers per lane, loaded once),
+//     B = in[pixel j + tap][c] broadcast over b -> after 36 MFMAs lane 4b+j holds out[pixel j][co0 + 4b .. +3]:
+//     one 16-B store per lane, four complete 256-B pixel rows per wave.
+// thin-Cout (Cout <= 4, Cin % 64 == 0):     the 16 blocks split K: block b owns channels 4b..4b+3 of a 64-channel
+//     chunk.  A = w[co = i][tap][chunk*64 + 4b + e], B = in[pixel j + tap][chunk*64 + 4b + e] (one 16-B load per
+//     lane per tap, four complete 256-B rows per wave); the 16 partial sums per output are folded by a
+//     data-halving butterfly over the lane bits of b (fixed order -> bitwise reproducible).
+// Both stream the wide tensor exactly once through 16-B buffer loads whose out-of-image taps are dropped by
+// the descriptor's range check (offset 0xffffffff -> 0.0f): no branches, no selects, no LDS.
+// Same descriptor contract as ssg_conv2d_igemm_f32 (bias, residual, activation, pad lanes written as 0).
+#include "common.h"
+#include "conv_thin.h"
+
+namespace {
+
+struct T4Args {
+  const float* in; const float* w; const float* bias; const float* res; float* out;
+  int C, ld, N, H, W, Kp, kmode, ldr, Cout, ldo, ntaps;
+  int tapidx[9];             // tap index at window position (dy+1)*3 + (dx+1), or -1
+  int act; float slope;
+  int groups, waves_per_group, total_units, strips, ybands, dbg;
+};
+
+constexpr int RH_CIN = 16;       // rows per work unit (thin-Cin): a 4-pixel-wide strip marched downwards
+constexpr int RH_COUT = 8;       // rows per work unit (thin-Cout) = accumulator sets folded by one butterfly
+constexpr unsigned OOB = 0xffffffffu;
+
+__device__ __forceinline__ f32x4 ldbuf4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  if (act == SSG_ACT_RELU) return v < 0.f ? 0.f : v;
+  if (act == SSG_ACT_LRELU) return v > 0.f ? v : v * slope;
+  return v;
+}
+
+// Both kernels march a 4-pixel-wide strip down the image with a ring of KS+1 input rows in registers:
+// every input row is loaded once per strip (KS 16-B loads per lane: the pixel's own column and its
+// neighbours), the load of row y+R+1 is in flight while row y is multiplied.
+
+// ------------------------------------------------------------------ thin-Cin: C == 4
+template <int KS>
+__global__ __launch_bounds__(256) void thin4_cin_kernel(const T4Args a) {
+  constexpr int R = KS / 2, NT = KS * KS, RING = KS + 1;
+  const int lane = threadIdx.x & 63, j = lane & 3, b = lane >> 2;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int cg = wid % a.groups, wg = wid / a.groups;
+  if (wg >= a.waves_per_group) return;
+  const unsigned npix = (unsigned)(a.N * a.H * a.W);
+  const auto in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)(npix * (unsigned)a.ld * 4u), 0x00020000);
+  const unsigned ldb = (unsigned)a.ld * 4u;
+
+  // A operand: this lane's output channel, all taps x 4 channels (kmode 1: k = t*4 + c)
+  const int co = cg * 64 + lane;
+  f32x4 wv[NT];
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    const int t = a.tapidx[KS == 3 ? p : 4];
+    wv[p] = (co < a.Cout && t >= 0) ? *(const f32x4*)(a.w + (size_t)co * a.Kp + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int cb = cg * 64 + 4 * b;                    // first of this lane's 4 output channels
+  const bool st_ok = cb < ((a.Cout + 3) & ~3);
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cmask;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    cmask[i] = (cb + i < a.Cout) ? 1.f : 0.f;                      // pad lanes [Cout, pad4) are written as 0
+    if (a.bias) bv[i] = (cb + i < a.Cout) ? a.bias[cb + i] : 0.f;
+  }
+  // activation without branches: v < 0 ? (relu ? 0 : v * neg_slope) : v   (neg_slope = 1 for "none")
+  const bool is_relu = a.act == SSG_ACT_RELU;
+  const float neg_slope = a.act == SSG_ACT_LRELU ? a.slope : 1.f;
+  f32x4 pend = {0.f, 0.f, 0.f, 0.f};
+  float* pend_ptr = nullptr;
+
+  for (int u = wg; u < a.total_units; u += a.waves_per_group) {
+    const int xs = u % a.strips; const int r0 = u / a.strips;
+    const int yb = r0 % a.ybands, n = r0 / a.ybands;
+    const int x = xs * 4 + j;
+    const int y0 = yb * RH_CIN;
+    const int y1 = y0 + RH_CIN < a.H ? y0 + RH_CIN : a.H;
+    unsigned coloff[KS];
+#pragma unroll
+    for (int e = 0; e < KS; ++e) {
+      const int ix = x + e - R;
+      coloff[e] = ((unsigned)ix < (unsigned)a.W && !(a.dbg & 2)) ? (unsigned)ix * ldb : OOB;
+    }
+    const unsigned imgoff = (unsigned)(n * a.H) * (unsigned)a.W * ldb;
+    auto load_row = [&](f32x4* dst, int iy) {
+      const bool rok = (unsigned)iy < (unsigned)a.H;
+      const unsigned ro = imgoff + (unsigned)iy * (unsigned)a.W * ldb;
+#pragma unroll
+      for (int e = 0; e < KS; ++e) dst[e] = ldbuf4(in_rs, (rok && coloff[e] != OOB) ? ro + coloff[e] : OOB);
+    };
+    f32x4 v[RING][KS];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) load_row(v[q], y0 - R + q);
+    for (int y = y0; y < y1; y += RING) {
+#pragma unroll
+      for (int r = 0; r < RING; ++r) {
+        if (y + r < y1) {
+          // The previous row's result is stored here, a whole MFMA phase before the next s_waitcnt has to
+          // cover it (gfx9 counts stores in vmcnt: a store issued right before the wait exposes its latency).
+          if (pend_ptr) *(f32x4*)pend_ptr = pend;
+          load_row(v[(r + KS) % RING], y + r - R + KS);
+          const size_t pix = (size_t)(n * a.H + y + r) * a.W + x;
+          f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+          if (a.res && x < a.W && st_ok) rv = *(const f32x4*)(a.res + pix * a.ldr + cb);
+          // two accumulator chains (even / odd k) keep dependent MFMAs apart
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < KS; ++q)
+#pragma unroll
+            for (int e = 0; e < KS; ++e)
+#pragma unroll
+              for (int c = 0; c < 4; c += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[q * KS + e][c], v[(r + q) % RING][e][c], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[q * KS + e][c + 1], v[(r + q) % RING][e][c + 1], acc1, 0, 0, 0);
+              }
+          const f32x4 t = acc0 + acc1 + bv + rv * cmask;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pend[i] = (t[i] < 0.f ? (is_relu ? 0.f : t[i] * neg_slope) : t[i]) * cmask[i];
+          pend_ptr = (x < a.W && st_ok) ? a.out + pix * a.ldo + cb : nullptr;
+        }
+      }
+    }
+  }
+  if (pend_ptr) *(f32x4*)pend_ptr = pend;
+}
+
+// ------------------------------------------------------------------ thin-Cout: Cout <= 4, C % 64 == 0
+template <int KS>
+__global__ __launch_bounds__(256) void thin4_cout_kernel(const T4Args a) {
+  constexpr int R = KS / 2, NT = KS * KS, S = RH_COUT, RING = KS + 1;
+  const int lane = threadIdx.x & 63, j = lane & 3, b = lane >> 2;
+  const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wg >= a.waves_per_group) return;
+  const unsigned npix = (unsigned)(a.N * a.H * a.W);
+  const auto in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)(npix * (unsigned)a.ld * 4u), 0x00020000);
+  const unsigned ldb = (unsigned)a.ld * 4u;
+  const int nchunks = a.C >> 6;
+  const int co = j;                                  // A operand row: lane 4b+i supplies w[co = i]
+  // after the butterfly lane (b, j) owns outputs (row s = b >> 1, pixel j, channels 2*(b&1), +1)
+  const int my_s = b >> 1, my_c = 2 * (b & 1);
+  float bias0 = 0.f, bias1 = 0.f;
+  if (a.bias) { bias0 = my_c < a.Cout ? a.bias[my_c] : 0.f; bias1 = my_c + 1 < a.Cout ? a.bias[my_c + 1] : 0.f; }
+
+  for (int u = wg; u < a.total_units; u += a.waves_per_group) {
+    const int xs = u % a.strips; const int r0 = u / a.strips;
+    const int yb = r0 % a.ybands, n = r0 / a.ybands;
+    const int x = xs * 4 + j;
+    const int y0 = yb * S;
+    unsigned coloff[KS];
+#pragma unroll
+    for (int e = 0; e < KS; ++e) {
+      const int ix = x + e - R;
+      coloff[e] = (unsigned)ix < (unsigned)a.W ? (unsigned)ix * ldb + 16u * b : OOB;
+    }
+    const unsigned imgoff = (unsigned)(n * a.H) * (unsigned)a.W * ldb;
+    f32x4 acc[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int c0 = ch * 64 + 4 * b;                // this lane's 4 reduced channels
+      f32x4 wv[NT];
+#pragma unroll
+      for (int p = 0; p < NT; ++p) {
+        const int t = a.tapidx[KS == 3 ? p : 4];
+        const int k = a.kmode == 0 ? (c0 >> 4) * a.ntaps * 16 + t * 16 + (c0 & 15) : t * a.C + c0;
+        wv[p] = (co < a.Cout && t >= 0) ? *(const f32x4*)(a.w + (size_t)co * a.Kp + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      auto load_row = [&](f32x4* dst, int iy) {
+        const bool rok = (unsigned)iy < (unsigned)a.H;
+        const unsigned ro = imgoff + (unsigned)iy * (unsigned)a.W * ldb + (unsigned)ch * 256u;
+#pragma unroll
+        for (int e = 0; e < KS; ++e) dst[e] = ldbuf4(in_rs, (rok && coloff[e] != OOB) ? ro + coloff[e] : OOB);
+      };
+      f32x4 v[RING][KS];
+#pragma unroll
+      for (int q = 0; q < KS; ++q) load_row(v[q], y0 - R + q);
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        load_row(v[(s + KS) % RING], y0 + s - R + KS);
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+#pragma unroll
+          for (int e = 0; e < KS; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[q * KS + e][c], v[(s + q) % RING][e][c], acc[s], 0, 0, 0);
+      }
+    }
+    // fold the 16 K-blocks: lane bit 5 (b bit 3) halves the rows 8 -> 4, bit 4: 4 -> 2, bit 3: 2 -> 1,
+    // bit 2 (b bit 0) halves the 4 channels -> 2.  Kept half is chosen by the lane's own bit.
+    float h4[4][4];
+    {
+      const bool hi = (lane >> 5) & 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float keep = hi ? acc[s + 4][i] : acc[s][i];
+          const float send = hi ? acc[s][i] : acc[s + 4][i];
+          h4[s][i] = keep + __shfl_xor(send, 32);
+        }
+    }
+    float h2[2][4];
+    {
+      const bool hi = (lane >> 4) & 1;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float keep = hi ? h4[s + 2][i] : h4[s][i];
+          const float send = hi ? h4[s][i] : h4[s + 2][i];
+          h2[s][i] = keep + __shfl_xor(send, 16);
+        }
+    }
+    float h1[4];
+    {
+      const bool hi = (lane >> 3) & 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float keep = hi ? h2[1][i] : h2[0][i];
+        const float send = hi ? h2[0][i] : h2[1][i];
+        h1[i] = keep + __shfl_xor(send, 8);
+      }
+    }
+    float o0, o1;
+    {
+      const bool hi = (lane >> 2) & 1;
+      const float k0 = hi ? h1[2] : h1[0], k1 = hi ? h1[3] : h1[1];
+      const float s0 = hi ? h1[0] : h1[2], s1 = hi ? h1[1] : h1[3];
+      o0 = k0 + __shfl_xor(s0, 4);
+      o1 = k1 + __shfl_xor(s1, 4);
+    }
+    // lane bits: bit5 -> s bit 2, bit4 -> s bit 1, bit3 -> s bit 0, bit2 -> channel pair  == (b >> 1, b & 1)
+    const int y = y0 + my_s;
+    if (x < a.W && y < a.H) {
+      const size_t pix = (size_t)(n * a.H + y) * a.W + x;
+      float t0 = o0 + bias0, t1 = o1 + bias1;
+      if (a.res) {
+        if (my_c < a.Cout) t0 += a.res[pix * a.ldr + my_c];
+        if (my_c + 1 < a.Cout) t1 += a.res[pix * a.ldr + my_c + 1];
+      }
+      float2 o;
+      o.x = my_c < a.Cout ? act_apply(t0, a.act, a.slope) : 0.f;
+      o.y = my_c + 1 < a.Cout ? act_apply(t1, a.act, a.slope) : 0.f;
+      if (my_c < ((a.Cout + 3) & ~3)) *(float2*)(a.out + pix * a.ldo + my_c) = o;
+    }
+  }
+}
+
+bool window_taps(const ssg_conv_desc* d, int* tapidx) {
+  for (int p = 0; p < 9; ++p) tapidx[p] = -1;
+  bool only_center = true;
+  for (int t = 0; t < d->ntaps; ++t) {
+    const int dy = d->dy[t], dx = d->dx[t];
+    if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
+    if (tapidx[(dy + 1) * 3 + dx + 1] >= 0) return false;
+    tapidx[(dy + 1) * 3 + dx + 1] = t;
+    if (dy || dx) only_center = false;
+  }
+  (void)only_center;
+  return true;
+}
+
+int thin4_on() {
+  static const int on = [] { const char* e = getenv("SSG_THIN4"); return e ? atoi(e) : 3; }();
+  return on;
+}
+
+}  // namespace
+
+// 0 = no; 3 = thin-Cin (in has 4 channels); 4 = thin-Cout (Cout <= 4, Cin % 64 == 0).  SSG_THIN4 is a bit
+// mask (1 = thin-Cin, 2 = thin-Cout; default both).
+int ssg_thin4_conv_kind(const ssg_conv_desc* d) {
+  if (d->C2 != 0 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox) return 0;
+  if (d->GH != d->H || d->GW != d->W || d->OH != d->H || d->OW != d->W || d->bnpart) return 0;
+  if ((long long)d->N * d->H * d->W * d->ld1 >= (1ll << 30)) return 0;          // 32-bit byte offsets
+  if (((uintptr_t)d->in1 & 15) || d->ld1 % 4 || ((uintptr_t)d->w & 15) || d->Kp % 4) return 0;
+  int tapidx[9];
+  if (!window_taps(d, tapidx)) return 0;
+  if ((thin4_on() & 1) && d->C1 == 4 && d->kmode == 1 && d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) &&
+      (!d->res || (d->ldr % 4 == 0 && !((uintptr_t)d->res & 15)))) return 3;
+  if ((thin4_on() & 2) && d->Cout <= 4 && d->C1 >= 64 && d->C1 % 64 == 0 && d->ldo % 2 == 0 && !((uintptr_t)d->out & 7)) return 4;
+  return 0;
+}
+
+int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
+  T4Args a;
+  a.in = d->in1; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out;
+  a.C = d->C1; a.ld = d->ld1; a.N = d->N; a.H = d->H; a.W = d->W; a.Kp = d->Kp; a.kmode = d->kmode;
+  a.ldr = d->ldr; a.Cout = d->Cout; a.ldo = d->ldo; a.ntaps = d->ntaps;
+  a.act = d->act; a.slope = d->slope;
+  { const char* e = getenv("SSG_T4_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+  window_taps(d, a.tapidx);
+  bool ks1 = true;
+  for (int p = 0; p < 9; ++p) if (p != 4 && a.tapidx[p] >= 0) ks1 = false;
+  const int rh = kind == 3 ? RH_CIN : RH_COUT;
+  a.strips = (d->W + 3) / 4;
+  a.ybands = (d->H + rh - 1) / rh;
+  a.total_units = d->N * a.ybands * a.strips;
+  a.groups = kind == 3 ? (d->Cout + 63) / 64 : 1;
+  int wpg = 8192 / a.groups;                         // ~32 waves per CU in total
+  if (wpg > a.total_units) wpg = a.total_units;
+  a.waves_per_group = wpg;
+  const dim3 grid((unsigned)((wpg * a.groups + 3) / 4)), block(256);
+  if (kind == 3) {
+    if (ks1) hipLaunchKernelGGL(thin4_cin_kernel<1>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(thin4_cin_kernel<3>, grid, block, 0, st, a);
+  } else {
+    if (ks1) hipLaunchKernelGGL(thin4_cout_kernel<1>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(thin4_cout_kernel<3>, grid, block, 0, st, a);
+  }
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
