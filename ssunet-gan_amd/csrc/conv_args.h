@@ -15,6 +15,7 @@ struct ConvArgs {
   unsigned long long tap_bits;   // 6 bits per tap: (dy+2) | (dx+2)<<3
   int act; float slope;
   int tiles_x, tiles_y, nsteps;
+  int ntiles_n, xcd_swizzle;     // conv_igemm_dma.hip: Cout tiles (fastest workgroup index), XCD-contiguous tile map
 };
 
 

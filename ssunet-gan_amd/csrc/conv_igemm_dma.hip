@@ -49,17 +49,26 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
   constexpr int STAGE = (BM + BN) * 16;  // floats per stage
   static_assert(B_PC >= 1, "BN >= 64");
 
-  __shared__ __attribute__((aligned(1024))) float lds[NSTAGE * STAGE];
+  extern __shared__ __attribute__((aligned(1024))) float lds[];      // NSTAGE * STAGE floats
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+  // Workgroup -> tile map.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs
+  // (one L2 each); id -> (id % 8) * (nwg / 8) + id / 8 hands every XCD one contiguous run of tiles, and
+  // the Cout tile is the fastest index, so the workgroups that are resident together on an XCD share
+  // their input rows (halo and Cout re-reads hit its L2).  The ragged tail keeps the identity map.
   int bid = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int per = (int)gridDim.x >> 3;
+    if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int nyt = a.ntiles_n;
+  const int n0 = (bid % nyt) * BN; bid /= nyt;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
   const int n = bid / a.tiles_y;
-  const int n0 = blockIdx.y * BN;
 
   // ---- per-lane DMA source state.  Piece j of this wave covers tile rows [(wave*PC + j)*16, +16);
   // lane l writes row r = base + (l>>2), 16-B position p = l&3, i.e. channel quad q = p ^ ((r>>2)&3).
@@ -198,8 +207,17 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   constexpr int TH = BM / 16;
   a.tiles_x = (a.GW + 15) / 16;
   a.tiles_y = (a.GH + TH - 1) / TH;
-  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)((a.Cout + BN - 1) / BN));
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), 0, st, a);
+  static const int swz = [] { const char* e = getenv("SSG_XCD_SWIZZLE"); return e ? atoi(e) : 1; }();
+  a.xcd_swizzle = swz;
+  a.ntiles_n = (a.Cout + BN - 1) / BN;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
+  constexpr int lds_bytes = NSTAGE * (BM + BN) * 16 * (int)sizeof(float);
+  if (lds_bytes > 64 * 1024) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (attr != hipSuccess) { ssg_set_error("conv dma: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
+  }
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -207,6 +225,7 @@ int launch(const ConvArgs& a0, hipStream_t st) {
 }  // namespace
 
 // Called by ssg_conv2d_igemm_f32 (conv_igemm.hip) for kmode 0, Cout > 32, no bnpart.
+// (A <256,128> tile with 128 x 64 per wave was measured: 284 VGPRs -> one wave per SIMD, 10-50% slower.)
 int ssg_conv_igemm_dma_launch(const ConvArgs& a, int variant, hipStream_t st) {
   if (variant == 0) return launch<128, 128, 2, 2>(a, st);
   return launch<256, 64, 4, 1>(a, st);
