@@ -251,6 +251,12 @@ bool uses_dma(const ssg_conv_desc* d) {
   return use_dma && d->kmode == 0 && d->Cout > 32 && d->bnpart == nullptr;
 }
 
+// LDS-resident halo tile (conv_igemm_halo.hip) for the 3x3 window; SSG_IGEMM_HALO=0 switches it off (A/B)
+bool uses_halo(const ConvArgs& a) {
+  static const int on = [] { const char* e = getenv("SSG_IGEMM_HALO"); return e ? atoi(e) : 1; }();
+  return on && ssg_conv_halo_ok(a);
+}
+
 int validate(const ssg_conv_desc* d) {
   SSG_REQUIRE(d != nullptr, SSG_EINVAL, "conv: null desc");
   SSG_REQUIRE(d->in1 && d->w && d->out, SSG_EINVAL, "conv: null pointer");
@@ -314,7 +320,10 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
   if (rc != SSG_OK) return rc;
   const ConvArgs a = to_args(d);
   hipStream_t st = (hipStream_t)stream;
-  if (uses_dma(d)) return ssg_conv_igemm_dma_launch(a, pick_variant(d), st);
+  if (uses_dma(d)) {
+    if (uses_halo(a)) return ssg_conv_igemm_halo_launch(a, pick_variant(d), st);
+    return ssg_conv_igemm_dma_launch(a, pick_variant(d), st);
+  }
   switch (pick_variant(d)) {
     case 0: return launch<128, 128, 2, 2>(a, st);
     case 1: return launch<256, 64, 4, 1>(a, st);
@@ -325,6 +334,7 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
 // Dispatcher: thin VALU kernels for the <= 8-channel cases, MFMA implicit GEMM otherwise.
 // ssg_conv2d_kernel_id reports which kernel a descriptor maps to (for profiling labels):
 //   0..2 = conv_igemm<128,128> / <256,64> / <256,32>, 20/21 = conv_igemm_dma<128,128> / <256,64>,
+//   30/31 = conv_igemm_halo<128,128> / <256,64>,
 //   12 = thin4 (4x4x1 MFMA) 4-channel input, 13 = thin4 Cout <= 4, 10 = thin small-Cout (VALU), 11 = thin small-Cin (VALU).
 extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
   if (!d) return SSG_EINVAL;
@@ -332,7 +342,8 @@ extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
   if (k4) return 9 + k4;
   const int k = ssg_thin_conv_kind(d);
   if (k) return 9 + k;
-  return pick_variant(d) + (uses_dma(d) ? 20 : 0);
+  if (uses_dma(d)) return pick_variant(d) + (uses_halo(to_args(d)) ? 30 : 20);
+  return pick_variant(d);
 }
 
 extern "C" int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream) {

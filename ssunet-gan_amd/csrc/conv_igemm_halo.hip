@@ -1,0 +1,255 @@
+// Implicit-GEMM 3x3 convolution with an LDS-resident halo tile (gfx950).  Same contract as
+// conv_igemm_dma.hip (kmode 0, unit input stride, Cout > 32); selected when the taps are the 9
+// positions of a 3x3 window -- every stride-1 3x3 forward conv and its input gradient.
+//
+// conv_igemm_dma.hip re-gathers the A tile (pixels x 16 channels) from global memory for each of the
+// 9 taps: 9 x BM rows per 16-channel chunk, the part of its loop that costs the most (ablation:
+// DESIGN.md).  Here the pixel tile is TH x 32 and its (TH+2) x 34 halo is brought into LDS ONCE per chunk;
+// tap (dy,dx) is just a row offset (dy*34 + dx) on the ds_read address: global->LDS traffic for A drops
+// 9x -> (TH+2)*34/(TH*32) = 1.33x (TH = 8) / 1.59x (TH = 4), and the DMA instruction count with it.
+// (32-pixel-wide tile rows: the 32 lanes of an MFMA M-fragment read 32 CONSECUTIVE halo rows, which keeps
+// every ds_read_b128 lane group on 16 distinct rows mod 16; a 16-wide tile would put lanes 16-31 at +18.)
+//
+//   * A: two halo buffers (chunk parity).  The pieces of chunk c+1 are issued one per wave per step
+//     during the first steps of chunk c.
+//   * B: the 3-stage ring of conv_igemm_dma.hip (weights of step s+2 issued at step s).
+//   * the 9 steps of a chunk are unrolled, so every s_waitcnt vmcnt(N) is an immediate: at step s the
+//     wave needs B(s); issued after it are B(s+1) and possibly one A piece.  Dummy pieces (zero page)
+//     keep the counts uniform at the tail.
+//   * LDS image, XOR swizzle (16-B position p of row r holds channel quad p ^ ((r>>2)&3)), zero page
+//     for out-of-image pixels and the epilogue are those of conv_igemm_dma.hip.
+#include "common.h"
+#include "conv_args.h"
+
+namespace {
+
+__device__ __attribute__((aligned(64))) float ssg_zero_page_h[64];
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void dma16(const float* src, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) {
+  constexpr int TH = BM / 32, TW = 32;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int HW = TW + 2, HR = (TH + 2) * HW;            // halo rows (one row = one pixel x 16 channels)
+  constexpr int AP = (HR + 15) / 16;                     // 1-KiB pieces per halo tile
+  constexpr int APW = (AP + 3) / 4;                      // pieces per wave (dummy-padded), one per step
+  constexpr int B_PC = BN / 64;                          // B pieces per wave per step
+  constexpr int ABUF = AP * 256;                         // floats per halo buffer
+  constexpr int BSTG = BN * 16;                          // floats per B stage
+  static_assert(APW <= 7, "A pieces must be issued before the last two steps of a chunk");
+
+  extern __shared__ __attribute__((aligned(1024))) float lds[];     // 2 * ABUF + 3 * BSTG floats
+  float* const ldsB = lds + 2 * ABUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  int bid = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int per = (int)gridDim.x >> 3;
+    if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int nyt = a.ntiles_n;
+  const int n0 = (bid % nyt) * BN; bid /= nyt;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int n = bid / a.tiles_y;
+
+  // ---- per-lane DMA source state
+  const int lr = lane >> 2, lp = lane & 3;
+  int a_pix[APW];                   // pixel index of this lane's halo row of piece k, or -1 (zero page)
+  int a_q[APW];
+#pragma unroll
+  for (int k = 0; k < APW; ++k) {
+    const int g = wave + 4 * k;                          // piece index: waves interleave
+    const int r = g * 16 + lr;
+    const int hy = r / HW, hx = r - hy * HW;
+    const int iy = ty * TH + hy - 1, ix = tx * TW + hx - 1;
+    const bool ok = g < AP && r < HR && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    a_pix[k] = ok ? (n * a.H + iy) * a.W + ix : -1;
+    a_q[k] = 4 * (lp ^ ((r >> 2) & 3));
+  }
+  const float* b_src[B_PC];
+#pragma unroll
+  for (int j = 0; j < B_PC; ++j) {
+    const int r = (wave * B_PC + j) * 16 + lr;
+    const int q = 4 * (lp ^ ((r >> 2) & 3));
+    b_src[j] = (n0 + r < a.Cout) ? a.w + (size_t)(n0 + r) * a.Kp + q : nullptr;
+  }
+  const float* zero = ssg_zero_page_h;
+  const int nchunks = (a.C1 + a.C2) >> 4;
+  const int nsteps = nchunks * 9;
+
+  // piece k of this wave for chunk `chunk` (a dummy zero-page piece past the last chunk or past AP)
+  auto issue_a = [&](int chunk, int k) {
+    const int g = wave + 4 * k;
+    if (g >= AP) { return; }                             // wave-uniform: this wave has no k-th piece
+    float* dst = lds + (chunk & 1) * ABUF + g * 256;
+    const int c0 = chunk * 16;
+    const float* src; int ld, cc;
+    if (c0 < a.C1) { src = a.in1; ld = a.ld1; cc = c0; } else { src = a.in2; ld = a.ld2; cc = c0 - a.C1; }
+    const float* p = (chunk < nchunks && a_pix[k] >= 0) ? src + (size_t)a_pix[k] * ld + cc + a_q[k] : zero;
+    dma16(p, dst);
+  };
+  auto issue_b = [&](int s) {
+    float* st = ldsB + (s % 3) * BSTG;
+#pragma unroll
+    for (int j = 0; j < B_PC; ++j) {
+      const float* p = (b_src[j] && s < nsteps) ? b_src[j] + (size_t)s * 16 : zero;
+      dma16(p, st + (wave * B_PC + j) * 256);
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int half = lane >> 5, l31 = lane & 31;
+  // halo row of this lane's pixel for M-fragment i at tap (0,0)
+  int rb[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int p = wm * WTM + i * 32 + l31;
+    rb[i] = ((p >> 5) + 1) * HW + (p & 31) + 1;
+  }
+  const int swb = (l31 >> 2) & 3;
+  const int bq0 = 4 * ((0 + half) ^ swb), bq1 = 4 * ((2 + half) ^ swb);
+
+  // ---- prologue: halo of chunk 0, weights of steps 0 and 1
+#pragma unroll
+  for (int k = 0; k < APW; ++k) issue_a(0, k);
+  issue_b(0);
+  issue_b(1);
+
+  // whether THIS wave issues an A piece at tap-step t (wave-uniform, but not compile-time for the last k)
+  // -> make the count compile-time: waves without a k-th piece issue nothing and the wait is sized per wave
+  // class below (has_last = the wave owns a piece with index k = APW-1).
+  const bool has_last = wave + 4 * (APW - 1) < AP;
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const float* Abuf = lds + (chunk & 1) * ABUF;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int s = chunk * 9 + t;
+      // outstanding after B(s): B(s+1) and the A piece of the previous step (if that step had one)
+      constexpr int dummy = 0; (void)dummy;
+      const int tp = (t + 8) % 9;                        // previous tap-step
+      if (tp < APW - 1) wait_vmcnt<B_PC + 1>();
+      else if (tp == APW - 1) { if (has_last) wait_vmcnt<B_PC + 1>(); else wait_vmcnt<B_PC>(); }
+      else wait_vmcnt<B_PC>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t < APW) issue_a(chunk + 1, t);
+      issue_b(s + 2);
+
+      const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
+      const int toff = ((tb & 7) - 2) * HW + ((tb >> 3) - 2);          // dy*HW + dx
+      const float* Bb = ldsB + (s % 3) * BSTG + (wn * WTN + l31) * 16;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int r = rb[i] + toff;
+          const int q = 4 * (((2 * h) + half) ^ ((r >> 2) & 3));
+          fa[i] = *(const f32x4*)(Abuf + r * 16 + q);
+        }
+        const int bq = h == 0 ? bq0 : bq1;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[j] = *(const f32x4*)(Bb + j * 32 * 16 + bq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // drain the dummy pieces before the workgroup's LDS can be handed to another workgroup
+  wait_vmcnt<0>();
+
+  // ---- epilogue (identical to conv_igemm.hip): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn * WTN + j * 32 + l31;
+    const bool cok = co < a.Cout;
+    const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int gy = ty * TH + (p >> 5), gx = tx * TW + (p & 31);
+        if (gy < a.GH && gx < a.GW) {
+          const size_t pix = ((size_t)(n * a.OH + gy * a.out_sy + a.out_oy) * a.OW + gx * a.out_sx + a.out_ox);
+          float v = acc[i][j][r] + bv;
+          if (cok) {
+            if (a.res) v += a.res[pix * a.ldr + co];
+            if (a.act == SSG_ACT_RELU) v = v < 0.f ? 0.f : v;
+            else if (a.act == SSG_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+            a.out[pix * a.ldo + co] = v;
+          } else if (co < ((a.Cout + 3) & ~3)) {
+            a.out[pix * a.ldo + co] = 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  constexpr int TH = BM / 32;
+  constexpr int AP = ((TH + 2) * 34 + 15) / 16;
+  a.tiles_x = (a.GW + 31) / 32;
+  a.tiles_y = (a.GH + TH - 1) / TH;
+  static const int swz = [] { const char* e = getenv("SSG_XCD_SWIZZLE"); return e ? atoi(e) : 1; }();
+  a.xcd_swizzle = swz;
+  a.ntiles_n = (a.Cout + BN - 1) / BN;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
+  constexpr int lds_bytes = (2 * AP * 256 + 3 * BN * 16) * (int)sizeof(float);
+  static_assert(lds_bytes <= 64 * 1024, "LDS budget");
+  hipLaunchKernelGGL((conv_igemm_halo_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+}  // namespace
+
+// the 9 taps must be the 9 positions of the 3x3 window (any order), unit input stride
+bool ssg_conv_halo_ok(const ConvArgs& a) {
+  if (a.ntaps != 9 || a.in_sy != 1 || a.in_sx != 1 || a.kmode != 0) return false;
+  unsigned seen = 0;
+  for (int t = 0; t < 9; ++t) {
+    const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
+    const int dy = (tb & 7) - 2, dx = (tb >> 3) - 2;
+    if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
+    seen |= 1u << ((dy + 1) * 3 + dx + 1);
+  }
+  return seen == 0x1ffu;
+}
+
+int ssg_conv_igemm_halo_launch(const ConvArgs& a, int variant, hipStream_t st) {
+  if (variant == 0) return launch<128, 128, 2, 2>(a, st);
+  return launch<256, 64, 4, 1>(a, st);
+}
