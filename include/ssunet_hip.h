@@ -119,7 +119,8 @@ typedef struct {
 
 int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d);
 int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream);
-/* 0..2 = wgrad_kernel<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma_kernel<128,128>/<128,64> (default
+/* 0..2 = wgrad_kernel<128,128>/<128,64>/<128,32>, 30/31 = wgrad_halo_kernel<32,128>/<64,64> (3x3 stride-1
+ * window kept in LDS; default for those), 20/21 = wgrad_dma_kernel<128,128>/<128,64> (default
  * for Cout > 32), 15/16 = wgrad4_kernel (4x4x1 MFMA: dout <= 4 channels / in = 4 channels, the default for
  * those shapes), 13/14 = the opt-in VALU variants */
 int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(32 * ZL) void wgrad_reduce_kernel(const RedArgs a) 
   a.dw[(((size_t)co * a.Cin_real + c) * a.KH + a.ky[t]) * a.KW + a.kx[t]] = v;
 }
 
-struct Plan { int variant, mt, nt, splits, steps_per_split; };
+struct Plan { int variant, mt, nt, splits, steps_per_split, halo; };
 
 // thin weight gradients on the 4x4x1 MFMA (conv_wgrad4.hip); SSG_WGRAD4=0 switches them off (A/B)
 int wgrad4_kind(const ssg_wgrad_desc* d) {
@@ -183,8 +183,15 @@ bool wgrad_uses_dma(int variant) {
   return use_dma && variant <= 1;
 }
 
+// LDS-resident pixel window (conv_wgrad_halo.hip) for the 3x3 window; SSG_WGRAD_HALO=0 switches it off (A/B)
+bool wgrad_uses_halo(const ssg_wgrad_desc* d, int variant) {
+  static const int on = [] { const char* e = getenv("SSG_WGRAD_HALO"); return e ? atoi(e) : 1; }();
+  return on && variant <= 1 && wgrad_uses_dma(variant) && ssg_wgrad_halo_ok(d, variant);
+}
+
 Plan make_plan(const ssg_wgrad_desc* d) {
   Plan p;
+  p.halo = 0;
   const int Cin = d->C1 + d->C2;
   const int M = d->ntaps * Cin;
   int bn;
@@ -193,7 +200,13 @@ Plan make_plan(const ssg_wgrad_desc* d) {
   else { p.variant = 2; bn = 32; }
   p.mt = (M + 127) / 128;
   p.nt = (d->Cout + bn - 1) / bn;
-  const long long steps = ((long long)d->N * d->GH * d->GW + BKP - 1) / BKP;
+  long long steps = ((long long)d->N * d->GH * d->GW + BKP - 1) / BKP;
+  if (wgrad_uses_halo(d, p.variant)) {
+    // M tile = 9 taps x CB channels; a K-step = 16 pixels inside one image row
+    p.halo = 1;
+    p.mt = Cin / ssg_wgrad_halo_cb(p.variant);
+    steps = (long long)d->N * d->GH * ((d->GW + BKP - 1) / BKP);
+  }
   long long want = 2048 / ((long long)p.mt * p.nt);      // ~8 workgroups per CU overall
   if (want < 1) want = 1;
   long long maxs = steps / 16;                           // at least 16 K-steps (256 pixels) per split
@@ -291,7 +304,10 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
     if (rc != SSG_OK) return rc;
   } else {
     dim3 grid((unsigned)p.mt, (unsigned)p.nt, (unsigned)p.splits);
-    if (wgrad_uses_dma(p.variant)) {
+    if (p.halo) {
+      rc = ssg_wgrad_halo_launch(a, p.variant, grid, st);
+      if (rc != SSG_OK) return rc;
+    } else if (wgrad_uses_dma(p.variant)) {
       rc = ssg_wgrad_dma_launch(a, p.variant, grid, st);
       if (rc != SSG_OK) return rc;
     } else
@@ -339,12 +355,13 @@ extern "C" int ssg_pack_weights_f32(const float* w_oihw, int O, int I, int KH, i
   return SSG_OK;
 }
 
-// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 13/14 = thin (VALU), 15/16 = wgrad4 (4x4x1 MFMA)
+// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 30/31 = wgrad_halo<32,128>/<64,64>, 13/14 = thin (VALU), 15/16 = wgrad4 (4x4x1 MFMA)
 extern "C" int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d) {
   if (!d) return SSG_EINVAL;
   if (wgrad4_kind(d)) return 10 + wgrad4_kind(d);
   const int k = ssg_thin_wgrad_kind(d);
   if (k) return 10 + k;
+  if (make_plan(d).halo) return 30 + make_plan(d).variant;
   const int v = make_plan(d).variant;
   return v + (wgrad_uses_dma(v) ? 20 : 0);
 }

@@ -14,3 +14,9 @@ struct WgArgs {
 
 // conv_wgrad_dma.hip: LDS-DMA pipeline for Cout > 32 (variant 0 = <128,128>, 1 = <128,64>)
 int ssg_wgrad_dma_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t st);
+
+// conv_wgrad_halo.hip: 3x3 stride-1 weight gradient with an LDS-resident pixel window
+// (variant 0 = 9 taps x 32 channels x 128 output channels per workgroup, 1 = 9 x 64 x 64)
+int ssg_wgrad_halo_cb(int variant);
+bool ssg_wgrad_halo_ok(const ssg_wgrad_desc* d, int variant);
+int ssg_wgrad_halo_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t st);

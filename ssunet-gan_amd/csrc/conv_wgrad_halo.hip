@@ -1,0 +1,185 @@
+// Weight gradient of 3x3 stride-1 convolutions with an LDS-resident pixel window (gfx950).  Same
+// contract and slab layout as wgrad_dma_kernel (conv_wgrad_dma.hip); selected when the taps are the 9
+// positions of a 3x3 window, the grid equals the image and the channel counts are multiples of CB.
+//
+// wgrad_dma_kernel's M tile is 128 rows of (tap, channel): every tap brings its own shifted copy of
+// the 16 pixels of a K-step.  Here the M tile is [9 taps] x [CB channels]: one K-step (16 pixels of
+// an image row) needs the 3 x 18 pixel window around it ONCE, and tap (dy,dx) is an LDS address offset.
+//   * per step and per M row the A traffic falls 2.7x (54 vs 144 pixel rows), the B traffic and the
+//     number of barriers per FLOP 2.25x (288 = 9 x 32 M rows per 32 channels instead of 128);
+//   * each wave owns 32 channels x 9 taps x 32 output channels: 9 accumulators, per pixel pair one
+//     B read + nine A reads (ds_read_b32, lanes = consecutive channels: conflict free) for nine MFMAs;
+//   * A window image [54 pixels][CB] and B image [16 pixels][BN] are the DMA's lane-linear layouts;
+//     3 stages, two K-steps in flight across the one barrier per step; out-of-image window pixels and
+//     the ragged end of an image row read a zero page.
+#include "common.h"
+#include "conv_wgrad_args.h"
+
+namespace {
+
+__device__ __attribute__((aligned(64))) float ssg_zero_page_wh[64];
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+__device__ __forceinline__ void dma16(const float* src, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+}
+
+constexpr int BKP = 16;          // pixels per K-step (one run inside an image row)
+constexpr int WW = BKP + 2;      // window width
+constexpr int WPX = 3 * WW;      // window pixels
+constexpr int NSTAGE = 3;
+
+template <int CB, int BN>
+__global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgArgs a) {
+  constexpr int WAVES_N = BN / 32, WAVES_M = 4 / WAVES_N;
+  static_assert(WAVES_M * 32 == CB, "one 32-channel fragment per wave row");
+  constexpr int AP = (WPX * CB + 255) / 256;     // 1-KiB pieces of the A window
+  constexpr int APW = (AP + 3) / 4;              // per wave (the image is padded to 4*APW pieces)
+  constexpr int B_PC = BKP * BN / 256 / 4;
+  static_assert(B_PC >= 1, "BN >= 64");
+  constexpr int ASZ = 4 * APW * 256;             // floats
+  constexpr int STAGE = ASZ + BKP * BN;
+
+  extern __shared__ __attribute__((aligned(1024))) float lds[];      // NSTAGE * STAGE floats
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int c0 = blockIdx.x * CB, n0 = blockIdx.y * BN;
+  const int Cin = a.C1 + a.C2;
+  const int XB = (a.GW + BKP - 1) / BKP;
+
+  const int step0 = (int)blockIdx.z * a.steps_per_split;
+  const int total = a.N * a.GH * XB;
+  int nsteps = total - step0;
+  if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
+  if (nsteps < 0) nsteps = 0;
+
+  // wave-uniform coordinate of the next step to issue
+  int is_xb = step0 % XB, is_row = step0 / XB;          // row = n*GH + gy
+  int is_gy = is_row % a.GH, is_n = is_row / a.GH;
+
+  // ---- A window pieces: lane -> (window pixel, channel quad)
+  const float* a_src; int a_ld;
+  if (c0 < a.C1) { a_src = a.in1 + c0; a_ld = a.ld1; } else { a_src = a.in2 + (c0 - a.C1); a_ld = a.ld2; }
+  int a_wy[APW], a_wx[APW], a_cq[APW]; bool a_ok[APW];
+#pragma unroll
+  for (int k = 0; k < APW; ++k) {
+    const int idx = (wave + 4 * k) * 64 + lane;          // float4 index in the [WPX][CB/4] image
+    const int wp = idx / (CB / 4);
+    a_cq[k] = 4 * (idx % (CB / 4));
+    a_ok[k] = wp < WPX;
+    a_wy[k] = wp / WW - 1; a_wx[k] = wp % WW - 1;
+  }
+  // ---- B pieces: lane -> (pixel within step, column quad)
+  int b_px[B_PC], b_cq[B_PC]; bool b_colok[B_PC];
+#pragma unroll
+  for (int j = 0; j < B_PC; ++j) {
+    const int idx = (wave * B_PC + j) * 64 + lane;
+    b_px[j] = idx / (BN / 4); b_cq[j] = 4 * (idx % (BN / 4));
+    b_colok[j] = n0 + b_cq[j] < a.Cout;
+  }
+  const float* zero = ssg_zero_page_wh;
+
+  auto issue = [&](int s) {
+    float* st = lds + (s % NSTAGE) * STAGE;
+    const int gx0 = is_xb * BKP;
+#pragma unroll
+    for (int k = 0; k < APW; ++k) {
+      const int iy = is_gy + a_wy[k], ix = gx0 + a_wx[k];
+      const bool ok = a_ok[k] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const float* p = ok ? a_src + ((size_t)(is_n * a.H + iy) * a.W + ix) * a_ld + a_cq[k] : zero;
+      dma16(p, st + (wave + 4 * k) * 256);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PC; ++j) {
+      const int gx = gx0 + b_px[j];
+      const float* p = (b_colok[j] && gx < a.GW) ? a.dout + ((size_t)(is_n * a.GH + is_gy) * a.GW + gx) * a.ldd + n0 + b_cq[j] : zero;
+      dma16(p, st + ASZ + (wave * B_PC + j) * 256);
+    }
+    if (++is_xb == XB) { is_xb = 0; if (++is_gy == a.GH) { is_gy = 0; ++is_n; } }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // tap t reads window pixel (dy+1)*WW + (px + dx + 1): float offset of tap t for pixel 0
+  int toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
+    toff[t] = (((tb & 7) - 2 + 1) * WW + ((tb >> 3) - 2) + 1) * CB;
+  }
+
+  if (nsteps > 0) issue(0);
+  if (nsteps > 1) issue(1);
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + B_PC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + 2 < nsteps) issue(s + 2);
+    const float* st = lds + (s % NSTAGE) * STAGE;
+    const float* Aw = st + half * CB + wm * 32 + l31;
+    const float* Bb = st + ASZ + half * BN + wn * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BKP / 2; ++kk) {
+      const float fb = Bb[2 * kk * BN];
+      float fa[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) fa[t] = Aw[toff[t] + 2 * kk * CB];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb, acc[t], 0, 0, 0);
+    }
+  }
+
+  // slab layout of conv_wgrad.hip: [split][row = t*Cin + c][Cout]
+  float* slab = a.ws + (size_t)blockIdx.z * a.M * a.Cout;
+  const int co = n0 + wn * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (c < Cin && co < a.Cout) slab[((size_t)t * Cin + c) * a.Cout + co] = acc[t][r];
+    }
+}
+
+template <int CB, int BN>
+int launch(const WgArgs& a, dim3 grid, hipStream_t st) {
+  constexpr int AP = (WPX * CB + 255) / 256, APW = (AP + 3) / 4;
+  constexpr int lds_bytes = NSTAGE * (4 * APW * 256 + BKP * BN) * (int)sizeof(float);
+  static_assert(lds_bytes <= 64 * 1024, "LDS budget");
+  hipLaunchKernelGGL((wgrad_halo_kernel<CB, BN>), grid, dim3(256), lds_bytes, st, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+}  // namespace
+
+// variant 0: 32 channels x 128 output channels per workgroup (Cout > 64); 1: 64 x 64
+int ssg_wgrad_halo_cb(int variant) { return variant == 0 ? 32 : 64; }
+
+bool ssg_wgrad_halo_ok(const ssg_wgrad_desc* d, int variant) {
+  if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->GH != d->H || d->GW != d->W) return false;
+  unsigned seen = 0;
+  for (int t = 0; t < 9; ++t) {
+    if (d->dy[t] < -1 || d->dy[t] > 1 || d->dx[t] < -1 || d->dx[t] > 1) return false;
+    seen |= 1u << ((d->dy[t] + 1) * 3 + d->dx[t] + 1);
+  }
+  if (seen != 0x1ffu) return false;
+  const int cb = ssg_wgrad_halo_cb(variant);
+  if (d->C1 % cb || d->C2 % cb) return false;
+  if ((long long)d->N * d->GH * ((d->GW + BKP - 1) / BKP) >= (1ll << 31)) return false;
+  return true;
+}
+
+int ssg_wgrad_halo_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t st) {
+  if (variant == 0) return launch<32, 128>(a, grid, st);
+  return launch<64, 64>(a, grid, st);
+}

@@ -179,6 +179,7 @@ _CONV_LABELS = {0: 'conv_igemm_kernel<128,128>', 1: 'conv_igemm_kernel<256,64>',
                 12: 'thin4_cin_kernel', 13: 'thin4_cout_kernel'}
 _WGRAD_LABELS = {0: 'wgrad_kernel<128,128>', 1: 'wgrad_kernel<128,64>', 2: 'wgrad_kernel<128,32>',
                  20: 'wgrad_dma_kernel<128,128>', 21: 'wgrad_dma_kernel<128,64>',
+                 30: 'wgrad_halo_kernel<32,128>', 31: 'wgrad_halo_kernel<64,64>',
                  13: 'thin_wgrad_small_cout_kernel', 14: 'thin_wgrad_small_cin_kernel',
                  15: 'wgrad4_kernel<thin_cout>', 16: 'wgrad4_kernel<thin_cin>'}
 
