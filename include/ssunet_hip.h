@@ -125,6 +125,15 @@ int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream);
  * those shapes), 13/14 = the opt-in VALU variants */
 int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d);
 
+/* Skinny fully-connected forward (replaces nn.Linear's forward at models_seg_gan.py:281-283, fc1/fc2 of the
+ * discriminator): y[n][o] = act(sum_k x[n][k] * w[o][k] + bias[o]).  `w` is the parameter itself ([O][K] row
+ * major, no packing); the weight matrix is streamed once (HBM-bound), K slices are summed in order by a
+ * finishing kernel (deterministic).  k % 4 == 0, ldx % 4 == 0, x and w 16-B aligned.  The input and weight
+ * gradients stay on ssg_conv2d_f32 / ssg_conv2d_wgrad_f32 (1x1 conv on a 1 x n image). */
+int64_t ssg_linear_fwd_workspace_bytes(int n, int k, int o);
+int ssg_linear_fwd_f32(const float* x, int n, int k, int ldx, const float* w, int o, const float* bias, int act,
+                       float slope, float* y, int ldy, float* ws, int64_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ layout helpers
  * NCHW (the reference's layout at the boundary: dataset.py:144 tensors, G logits) <->
  * internal NHWC-with-stride.  Pad channels [C, ld) are written as 0. */

@@ -113,6 +113,8 @@ SIGNATURES = {
     'ssg_spectral_norm_workspace_bytes': [_I, _I],
     'ssg_spectral_norm_fwd_f32': [_P, _I, _I, _P, _P, _I, _D, _P, _P, _P, _P],
     'ssg_spectral_norm_bwd_f32': [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    'ssg_linear_fwd_workspace_bytes': [_I, _I, _I],
+    'ssg_linear_fwd_f32': [_P, _I, _I, _I, _P, _I, _P, _I, _F, _P, _I, _P, _L, _P],
     'ssg_tool_mfma_peak_f32': [_P, _I, _I, _P],
     'ssg_tool_copy_f32': [_P, _P, _L, _P],
 }
@@ -122,6 +124,7 @@ _RESTYPES = {
     'ssg_seg_loss_workspace_bytes': C.c_int64,
     'ssg_dwconv2d_wgrad_workspace_bytes': C.c_int64,
     'ssg_spectral_norm_workspace_bytes': C.c_int64,
+    'ssg_linear_fwd_workspace_bytes': C.c_int64,
 }
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_igemm_mtiles', 'ssg_conv2d_kernel_id', 'ssg_conv2d_wgrad_kernel_id'}
 

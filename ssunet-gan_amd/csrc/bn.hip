@@ -92,23 +92,26 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
   }
 }
 
-// Second stage: 32 channels x 8 part-lanes per block; each lane adds every 8th partial row in
-// row order, then the 8 lane sums are added in lane order -> fixed summation order (bitwise
-// reproducible), 1/8 of the serial chain of a one-thread-per-channel loop.
-__global__ __launch_bounds__(256) void col_reduce_final_kernel(const double* __restrict__ part, int parts, int C, int C4,
-                                                               double* __restrict__ sums, float* __restrict__ fsum) {
-  __shared__ double red[2][8][32];
+// Second stage: 32 channels x 32 part-lanes per block; each lane adds every 32nd partial row in
+// row order, then the 32 lane sums are added in lane order -> fixed summation order (bitwise
+// reproducible), 1/32 of the serial chain of a one-thread-per-channel loop.
+constexpr int FIN_LANES = 32;
+__global__ __launch_bounds__(32 * FIN_LANES) void col_reduce_final_kernel(const double* __restrict__ part, int parts, int C, int C4,
+                                                                          double* __restrict__ sums, float* __restrict__ fsum) {
+  __shared__ double red[2][FIN_LANES][32];
   const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double a1 = 0, a2 = 0;
-  if (c < C)
-    for (int b = lane; b < parts; b += 8) { a1 += part[(size_t)b * 2 * C4 + c]; a2 += part[(size_t)b * 2 * C4 + C4 + c]; }
+  if (c < C) {
+#pragma unroll 4
+    for (int b = lane; b < parts; b += FIN_LANES) { a1 += part[(size_t)b * 2 * C4 + c]; a2 += part[(size_t)b * 2 * C4 + C4 + c]; }
+  }
   red[0][lane][cl] = a1; red[1][lane][cl] = a2;
   __syncthreads();
   if (lane == 0 && c < C) {
     double t1 = 0, t2 = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { t1 += red[0][k][cl]; t2 += red[1][k][cl]; }
+    for (int k = 0; k < FIN_LANES; ++k) { t1 += red[0][k][cl]; t2 += red[1][k][cl]; }
     if (sums) { sums[c] = t1; sums[C + c] = t2; }
     if (fsum) fsum[c] = (float)t1;
   }
@@ -222,7 +225,7 @@ int run_reduce(const float* x, const float* y, const float* dy, long long P, int
   hipLaunchKernelGGL((col_reduce_kernel<MODE>), dim3((unsigned)g.parts, (unsigned)g.groups), dim3(RED_BLOCK), 0, st, x, y, dy,
                      P, C, ldx, ldy, lddy, mean, invstd, act, slope, g.TQ, g.PR, g.rows_per_part, part);
   SSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, part, g.parts, C, C4, sums, fsum);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C4, sums, fsum);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

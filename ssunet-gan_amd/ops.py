@@ -399,7 +399,15 @@ class _Linear(torch.autograd.Function):
         if k % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
             x = _pad_rows(x)
         xi = x.as_strided((1, k, 1, n), (n * x.stride(0), 1, n * x.stride(0), x.stride(0)))
-        y = _conv_fwd_impl(xi, None, weight.view(o, k, 1, 1), bias, 1, 0, act, slope)      # [1, o, 1, n]
+        if weight.is_contiguous() and weight.data_ptr() % 16 == 0 and k % 4 == 0:
+            # skinny GEMM that streams the [O][K] parameter once (HBM-bound); no packed copy
+            y = new_nhwc(1, o, 1, n, x.device)
+            nbytes = call('ssg_linear_fwd_workspace_bytes', n, k, o)
+            ws = _ws(nbytes, x.device)
+            call('ssg_linear_fwd_f32', ptr(xi), n, k, x.stride(0), ptr(weight), o, ptr(bias) if bias is not None else None,
+                 act, slope, ptr(y), _ld(y), ptr(ws), nbytes, stream_ptr())
+        else:
+            y = _conv_fwd_impl(xi, None, weight.view(o, k, 1, 1), bias, 1, 0, act, slope)      # [1, o, 1, n]
         ld = _ld(y)
         y2 = torch.empty(0, device=y.device, dtype=torch.float32).set_(y.untyped_storage(), y.storage_offset(), (n, o), (ld, 1))
         ctx.save_for_backward(xi, weight, y if act != ACT_NONE else None)

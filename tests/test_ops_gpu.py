@@ -159,7 +159,8 @@ def test_adaptive_avgpool_flat(pkg, dev, hw):
     _close(yd, yr, 1e-6, 1e-6, 'avgpool'); _close(xd.grad, xr.grad, 1e-6, 1e-6, 'avgpool bwd')
 
 
-@pytest.mark.parametrize('n,k,o,act', [(2, 64, 32, True), (5, 288, 1024, True), (3, 1024, 1, False), (16, 48, 20, False)])
+@pytest.mark.parametrize('n,k,o,act', [(2, 64, 32, True), (5, 288, 1024, True), (3, 1024, 1, False), (16, 48, 20, False),
+                                         (19, 1300, 7, True), (16, 18432, 1024, True)])
 def test_linear(pkg, dev, n, k, o, act):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(n, k, generator=g); wt = torch.randn(o, k, generator=g) / math.sqrt(k); b = torch.randn(o, generator=g)
