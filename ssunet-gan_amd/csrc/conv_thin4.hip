@@ -22,7 +22,7 @@ struct T4Args {
   int C, ld, N, H, W, Kp, kmode, ldr, Cout, ldo, ntaps;
   int tapidx[9];             // tap index at window position (dy+1)*3 + (dx+1), or -1
   int act; float slope;
-  int groups, waves_per_group, total_units, strips, ybands, dbg;
+  int groups, waves_per_group, total_units, strips, ybands;
 };
 
 constexpr int RH_CIN = 16;       // rows per work unit (thin-Cin): a 4-pixel-wide strip marched downwards
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void thin4_cin_kernel(const T4Args a) {
 #pragma unroll
     for (int e = 0; e < KS; ++e) {
       const int ix = x + e - R;
-      coloff[e] = ((unsigned)ix < (unsigned)a.W && !(a.dbg & 2)) ? (unsigned)ix * ldb : OOB;
+      coloff[e] = (unsigned)ix < (unsigned)a.W ? (unsigned)ix * ldb : OOB;
     }
     const unsigned imgoff = (unsigned)(n * a.H) * (unsigned)a.W * ldb;
     auto load_row = [&](f32x4* dst, int iy) {
@@ -297,7 +297,6 @@ int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
   a.C = d->C1; a.ld = d->ld1; a.N = d->N; a.H = d->H; a.W = d->W; a.Kp = d->Kp; a.kmode = d->kmode;
   a.ldr = d->ldr; a.Cout = d->Cout; a.ldo = d->ldo; a.ntaps = d->ntaps;
   a.act = d->act; a.slope = d->slope;
-  { const char* e = getenv("SSG_T4_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   window_taps(d, a.tapidx);
   bool ks1 = true;
   for (int p = 0; p < 9; ++p) if (p != 4 && a.tapidx[p] >= 0) ks1 = false;

@@ -60,6 +60,73 @@ def test_conv2d_fwd_bwd(pkg, dev, case):
         _close(bd.grad, br.grad, 2e-5, 1e-5, 'conv bias grad')
 
 
+# Shapes chosen so that every specialised kernel behind ssg_conv2d_f32 / ssg_conv2d_wgrad_f32 is the one
+# that runs (checked through the profiling labels): the 4x4x1-MFMA thin kernels, the LDS-halo kernels and
+# the plain LDS-DMA kernels, on ragged image sizes, with bias + residual + activation.
+KERNEL_CASES = [
+    # n, cin, cout, h, w, k, pad, kernels that must have run (forward, input gradient, weight gradient)
+    (2, 3, 64, 37, 45, 3, 1, ('thin4_cin_kernel', 'thin4_cout_kernel', 'wgrad4_kernel<thin_cin>')),
+    (1, 128, 4, 19, 23, 3, 1, ('thin4_cout_kernel', 'thin4_cin_kernel', 'wgrad4_kernel<thin_cout>')),
+    (2, 64, 1, 16, 20, 1, 0, ('thin4_cout_kernel', 'thin4_cin_kernel', 'wgrad4_kernel<thin_cout>')),
+    (2, 64, 128, 37, 45, 3, 1, ('conv_igemm_halo_kernel<128,128>', 'conv_igemm_halo_kernel<256,64>', 'wgrad_halo_kernel<32,128>')),
+    (1, 128, 64, 21, 70, 3, 1, ('conv_igemm_halo_kernel<256,64>', 'conv_igemm_halo_kernel<128,128>', 'wgrad_halo_kernel<64,64>')),
+    (1, 96, 64, 9, 33, 3, 1, ('conv_igemm_halo_kernel<256,64>', 'conv_igemm_halo_kernel<128,128>', 'wgrad_dma_kernel<128,64>')),
+    (2, 48, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,128>', 'conv_igemm_dma_kernel<256,64>', 'wgrad_dma_kernel<128,128>')),
+]
+
+
+@pytest.mark.parametrize('case', KERNEL_CASES)
+def test_conv2d_specialised_kernels(pkg, dev, case):
+    n, cin, cout, h, w, k, p, expect = case
+    g = torch.Generator().manual_seed(1234 + cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    rs = torch.randn(n, cout, h, w, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, wt, b, rs)]
+    yr = F.leaky_relu(F.conv2d(ref[0], ref[1], ref[2], 1, p) + ref[3], 0.2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    d = [t.to(dev).requires_grad_(True) for t in (x, wt, b, rs)]
+    pkg.ops.PROFILE = []
+    try:
+        yd = pkg.ops.conv2d(d[0], d[1], d[2], 1, p, act=pkg._lib.ACT_LRELU, slope=0.2, res=d[3])
+        yd.backward(dy.to(dev))
+        labels = [rec[0] for rec in pkg.ops.PROFILE]
+    finally:
+        pkg.ops.PROFILE = None
+    for name in expect:
+        assert name in labels, '%s did not run (ran: %s)' % (name, labels)
+    _close(yd, yr, 1e-5, 2e-6 * math.sqrt(cin * k * k), 'fwd')
+    _close(d[0].grad, ref[0].grad, 1e-5, 2e-6 * math.sqrt(cout * k * k), 'dgrad')
+    _close(d[1].grad, ref[1].grad, 2e-5, 2e-6 * math.sqrt(n * h * w), 'wgrad')
+    _close(d[2].grad, ref[2].grad, 2e-5, 1e-5, 'bias grad')
+    _close(d[3].grad, ref[3].grad, 1e-6, 1e-6, 'residual grad')
+
+
+def test_conv2d_concat_halo(pkg, dev):
+    """torch.cat absorbed by the second input pointer, on the halo kernels (forward, both input gradients, weight gradient)."""
+    g = torch.Generator().manual_seed(31)
+    x1 = torch.randn(1, 64, 33, 40, generator=g); x2 = torch.randn(1, 64, 33, 40, generator=g)
+    wt = torch.randn(128, 128, 3, 3, generator=g) / 34
+    r = [t.clone().requires_grad_(True) for t in (x1, x2, wt)]
+    yr = F.conv2d(torch.cat([r[0], r[1]], 1), r[2], None, 1, 1)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    d = [t.to(dev).requires_grad_(True) for t in (x1, x2, wt)]
+    pkg.ops.PROFILE = []
+    try:
+        yd = pkg.ops.conv2d(d[0], d[2], None, 1, 1, x2=d[1])
+        yd.backward(dy.to(dev))
+        labels = [rec[0] for rec in pkg.ops.PROFILE]
+    finally:
+        pkg.ops.PROFILE = None
+    assert 'conv_igemm_halo_kernel<128,128>' in labels and 'wgrad_halo_kernel<32,128>' in labels, labels
+    _close(yd, yr, 1e-5, 7e-5, 'concat halo conv')
+    for a, b, nm in zip(d, r, ('dx1', 'dx2', 'dw')):
+        _close(a.grad, b.grad, 2e-5, 7e-5, nm)
+
+
 def test_conv2d_concat_and_act(pkg, dev):
     g = torch.Generator().manual_seed(3)
     x1 = torch.randn(2, 32, 12, 12, generator=g); x2 = torch.randn(2, 16, 12, 12, generator=g)

@@ -1,4 +1,8 @@
-import torch, torch.nn as nn, sys
+"""Per-shape profile of one G+D step: which kernel every conv / weight-gradient launch maps to, its time
+and TFLOP/s (HIP events around each launch).  Usage: python tools/shapes.py [batch]"""
+import os, sys
+import torch, torch.nn as nn
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ssunet_gan_amd as S
 dev = torch.device('cuda')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
