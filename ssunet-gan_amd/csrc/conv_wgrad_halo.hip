@@ -57,9 +57,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgArgs a) {
   if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
   if (nsteps < 0) nsteps = 0;
 
-  // wave-uniform coordinate of the next step to issue
-  int is_xb = step0 % XB, is_row = step0 / XB;          // row = n*GH + gy
-  int is_gy = is_row % a.GH, is_n = is_row / a.GH;
+  // wave-uniform coordinate of the next step to issue.  Steps walk DOWN a 16-pixel-wide column strip
+  // (gy fastest, then the strip, then the image): consecutive steps share two of their three window rows,
+  // so the 3x row re-read of the window is served by L2 instead of HBM (measured before: 2.5x the
+  // algorithmic bytes with x-fastest order).
+  int is_gy = step0 % a.GH, is_col = step0 / a.GH;
+  int is_xb = is_col % XB, is_n = is_col / XB;
 
   // ---- A window pieces: lane -> (window pixel, channel quad)
   const float* a_src; int a_ld;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgArgs a) {
       const float* p = (b_colok[j] && gx < a.GW) ? a.dout + ((size_t)(is_n * a.GH + is_gy) * a.GW + gx) * a.ldd + n0 + b_cq[j] : zero;
       dma16(p, st + ASZ + (wave * B_PC + j) * 256);
     }
-    if (++is_xb == XB) { is_xb = 0; if (++is_gy == a.GH) { is_gy = 0; ++is_n; } }
+    if (++is_gy == a.GH) { is_gy = 0; if (++is_xb == XB) { is_xb = 0; ++is_n; } }
   };
 
   f32x16 acc[9];
