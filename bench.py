@@ -24,7 +24,11 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-FLOP_PER_IMG_512 = 1.6951e12        # 2*(3*208.625 + 9*24.631) GFLOP per image per step
+# 2*(3*208.625 + 9*24.631) GFLOP per image per step.  The discriminator's parameter gradients of the
+# G-step backward are dead in the reference (zeroed at train_seg_gan.py:225 before any use) and are not computed
+# unless SSG_KEEP_DEAD_D_GRADS=1 (ssunet-gan_amd/train_seg_gan.py): 8 instead of 9 discriminator passes EXECUTED.
+D_PASSES = 9 if os.environ.get('SSG_KEEP_DEAD_D_GRADS', '0') == '1' else 8
+FLOP_PER_IMG_512 = 2 * (3 * 208.625 + D_PASSES * 24.631) * 1e9
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 # HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
 # separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950):
@@ -190,7 +194,8 @@ def main():
             'config': {'workload': 'UNet_R_SS_v2 generator + SRGAN-style discriminator, one G+D step (train_seg_gan.py:182-233), '
                                    '%d x 3x%dx%d tiles per GPU, fp32, Adam lr 2e-5' % (args.batch, args.size, args.size),
                        'global_batch': args.batch * world, 'tile': args.size,
-                       'parallelism': 'dp%d%s' % (world, ' (RCCL grad all-reduce + sync-BN)' if world > 1 else '')},
+                       'parallelism': 'dp%d%s' % (world, ' (RCCL grad all-reduce + sync-BN)' if world > 1 else ''),
+                       'dead_d_param_grads_of_g_step': 'computed' if D_PASSES == 9 else 'not computed (zeroed unread in the reference, train_seg_gan.py:225)'},
             'loss': round(float(out[0]), 6), 'iou': round(float(out[1]), 6), 'dice': round(float(out[2]), 6),
             'roofline': roof,
         }

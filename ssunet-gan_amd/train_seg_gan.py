@@ -12,6 +12,8 @@ What differs from the reference, by design:
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -45,6 +47,24 @@ def _step_optimizer(optimizer, grad_clip):
         ops.bump_weight_epoch()
 
 
+KEEP_DEAD_D_GRADS = os.environ.get('SSG_KEEP_DEAD_D_GRADS', '0') == '1'
+
+
+class _params_frozen(object):
+    """Run a forward with the module's parameters not requiring grad (restored on exit)."""
+
+    def __init__(self, module, on):
+        self.params = [p for p in module.parameters() if p.requires_grad] if on else []
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *a):
+        for p in self.params:
+            p.requires_grad_(True)
+
+
 def gan_step(input, target, generator, discriminator, criterion, adversarial_loss_criterion, content_loss_criterion,
              optimizer_g, optimizer_d, num_class, sync_g=None, sync_d=None):
     """One iteration of train_seg_gan.py:182-233.  Returns device scalars (loss, iou, dice, closs, adv_g, adv_d)."""
@@ -63,7 +83,11 @@ def gan_step(input, target, generator, discriminator, criterion, adversarial_los
     if dp.is_dist():                                # whole-batch ratios: reduce the sums, not the ratios
         iou, dice = dp.reduce_metric_sums(msums)
 
-    seg_discriminated = discriminator(generator_output)                        # :202
+    # The discriminator's PARAMETER gradients of this backward are dead in the reference: optimizer_g only steps
+    # the generator and optimizer_d.zero_grad() (:225) clears them before anything reads them.  They are not
+    # computed (the gradient w.r.t. generator_output still flows through D); SSG_KEEP_DEAD_D_GRADS=1 restores them.
+    with _params_frozen(discriminator, not KEEP_DEAD_D_GRADS):
+        seg_discriminated = discriminator(generator_output)                    # :202
     adversarial_loss = _adv_loss(adversarial_loss_criterion, seg_discriminated, 1.0)
     perceptual_loss = loss + ALPA * content_loss + BETA * adversarial_loss     # :205
     adv_g = adversarial_loss.detach()
