@@ -125,6 +125,13 @@ int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream);
  * those shapes), 13/14 = the opt-in VALU variants */
 int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d);
 
+/* Attention gate of AttUNet (archs.py:115-144, `x * psi`): y[p][c] = x[p][c] * sigmoid(g[p]) with one gate
+ * logit per pixel (g is the 1-channel BatchNorm output, pixel stride ldg); the sigmoid is folded in.
+ * backward: dx = dy * s, dg[p] = (sum_c dy*x) * s * (1 - s) (written as a 4-float pixel: value, 0, 0, 0). */
+int ssg_pixel_gate_fwd_f32(const float* x, int ldx, const float* g, int ldg, int64_t P, int C, float* y, int ldy, void* stream);
+int ssg_pixel_gate_bwd_f32(const float* x, int ldx, const float* g, int ldg, const float* dy, int lddy, int64_t P, int C,
+                           float* dx, int lddx, float* dg, int lddg, void* stream);
+
 /* Skinny fully-connected forward (replaces nn.Linear's forward at models_seg_gan.py:281-283, fc1/fc2 of the
  * discriminator): y[n][o] = act(sum_k x[n][k] * w[o][k] + bias[o]).  `w` is the parameter itself ([O][K] row
  * major, no packing); the weight matrix is streamed once (HBM-bound), K slices are summed in order by a

@@ -243,7 +243,7 @@ def gen_archs(mods):
     x = torch.randn(4, 3, 64, 64, generator=g)
     data['x'] = x.numpy()
     for name, ds in (('UNet', False), ('NestedUNet', False), ('NestedUNet', True), ('SSUNet', False), ('UNet_ori', False),
-                     ('UNet_B_SS', False), ('UNet_R_SS', False)):
+                     ('UNet_B_SS', False), ('UNet_R_SS', False), ('AttUNet', False)):
         torch.manual_seed(52)
         m = archs.__dict__[name](3, 3, ds); m.train()
         xr = x.clone().requires_grad_(True)

@@ -113,6 +113,8 @@ SIGNATURES = {
     'ssg_spectral_norm_workspace_bytes': [_I, _I],
     'ssg_spectral_norm_fwd_f32': [_P, _I, _I, _P, _P, _I, _D, _P, _P, _P, _P],
     'ssg_spectral_norm_bwd_f32': [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    'ssg_pixel_gate_fwd_f32': [_P, _I, _P, _I, _L, _I, _P, _I, _P],
+    'ssg_pixel_gate_bwd_f32': [_P, _I, _P, _I, _P, _I, _L, _I, _P, _I, _P, _I, _P],
     'ssg_linear_fwd_workspace_bytes': [_I, _I, _I],
     'ssg_linear_fwd_f32': [_P, _I, _I, _I, _P, _I, _P, _I, _F, _P, _I, _P, _L, _P],
     'ssg_tool_mfma_peak_f32': [_P, _I, _I, _P],

@@ -14,8 +14,7 @@ from .normalization import SPADE
 from ._lib import ACT_NONE, ACT_RELU
 
 # archs.py:8 -- the reference's export list.  UNet_R_SS_v2 is the arch config_v1.json wires.
-__all__ = ['UNet', 'NestedUNet', 'SSUNet', 'UNet_ori', 'UNet_B_SS', 'UNet_R_SS', 'UNet_R_SS_v2']
-# not built: 'AttUNet' (archs.py:271-345) needs a 1-channel batch norm + sigmoid gate broadcast over channels
+__all__ = ['UNet', 'NestedUNet', 'SSUNet', 'UNet_ori', 'UNet_B_SS', 'AttUNet', 'UNet_R_SS', 'UNet_R_SS_v2']
 
 
 def _sync_group(bn):
@@ -175,6 +174,68 @@ class up_conv(nn.Module):
         y = ops.upsample2x_nearest(x)
         y = ops.conv2d(y, self.up[1].weight, self.up[1].bias, 1, 1)
         return ops.batch_norm_act(y, self.up[2], act=ACT_RELU, group=_sync_group(self.up[2]))
+
+
+class Attention_block(nn.Module):
+    """archs.py:115-144: additive attention gate.  psi = sigmoid(BN1(conv1x1(relu(BN(W_g g) + BN(W_x x))))), out = x * psi.
+    The ReLU rides the second batch norm's residual epilogue; sigmoid and the per-pixel broadcast are one kernel."""
+
+    def __init__(self, F_g, F_l, F_int):
+        super().__init__()
+        self.W_g = nn.Sequential(nn.Conv2d(F_g, F_int, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm2d(F_int))
+        self.W_x = nn.Sequential(nn.Conv2d(F_l, F_int, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm2d(F_int))
+        self.psi = nn.Sequential(nn.Conv2d(F_int, 1, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm2d(1), nn.Sigmoid())
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, g, x):
+        g1 = ops.batch_norm_act(ops.conv2d(g, self.W_g[0].weight, self.W_g[0].bias), self.W_g[1], group=_sync_group(self.W_g[1]))
+        a = ops.batch_norm_act(ops.conv2d(x, self.W_x[0].weight, self.W_x[0].bias), self.W_x[1], res=g1, act=ACT_RELU,
+                               group=_sync_group(self.W_x[1]))
+        p = ops.conv2d(a, self.psi[0].weight, self.psi[0].bias)
+        p = ops.batch_norm_act(p, self.psi[1], group=_sync_group(self.psi[1]))
+        return ops.pixel_gate(x, p)
+
+
+class AttUNet(nn.Module):
+    """archs.py:271-345: UNet_ori with an attention gate on every skip connection."""
+
+    def __init__(self, output_ch, img_ch=3, deep_supervision=False, **kwargs):
+        super().__init__()
+        self.Maxpool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.Conv1 = conv_block(ch_in=img_ch, ch_out=64)
+        self.Conv2 = conv_block(ch_in=64, ch_out=128)
+        self.Conv3 = conv_block(ch_in=128, ch_out=256)
+        self.Conv4 = conv_block(ch_in=256, ch_out=512)
+        self.Conv5 = conv_block(ch_in=512, ch_out=1024)
+        self.Up5 = up_conv(ch_in=1024, ch_out=512)
+        self.Att5 = Attention_block(F_g=512, F_l=512, F_int=256)
+        self.Up_conv5 = conv_block(ch_in=1024, ch_out=512)
+        self.Up4 = up_conv(ch_in=512, ch_out=256)
+        self.Att4 = Attention_block(F_g=256, F_l=256, F_int=128)
+        self.Up_conv4 = conv_block(ch_in=512, ch_out=256)
+        self.Up3 = up_conv(ch_in=256, ch_out=128)
+        self.Att3 = Attention_block(F_g=128, F_l=128, F_int=64)
+        self.Up_conv3 = conv_block(ch_in=256, ch_out=128)
+        self.Up2 = up_conv(ch_in=128, ch_out=64)
+        self.Att2 = Attention_block(F_g=64, F_l=64, F_int=32)
+        self.Up_conv2 = conv_block(ch_in=128, ch_out=64)
+        self.Conv_1x1 = nn.Conv2d(64, output_ch, kernel_size=1, stride=1, padding=0)
+
+    def forward(self, x):
+        x1 = self.Conv1(ops.as_nhwc(x))
+        x2 = self.Conv2(_pool(x1))
+        x3 = self.Conv3(_pool(x2))
+        x4 = self.Conv4(_pool(x3))
+        x5 = self.Conv5(_pool(x4))
+        d5 = self.Up5(x5)
+        d5 = self.Up_conv5(self.Att5(d5, x4), d5)          # cat((gated skip, d5)) is the conv's second input pointer
+        d4 = self.Up4(d5)
+        d4 = self.Up_conv4(self.Att4(d4, x3), d4)
+        d3 = self.Up3(d4)
+        d3 = self.Up_conv3(self.Att3(d3, x2), d3)
+        d2 = self.Up2(d3)
+        d2 = self.Up_conv2(self.Att2(d2, x1), d2)
+        return ops.conv2d(d2, self.Conv_1x1.weight, self.Conv_1x1.bias)
 
 
 class UNet_R_SS_v2(nn.Module):

@@ -144,6 +144,41 @@ __global__ __launch_bounds__(256) void clamp_multi_kernel(const void* const* __r
   for (int i = threadIdx.x; i < n; i += 256) { float v = P[base + i]; v = v < lo ? lo : v; v = v > hi ? hi : v; P[base + i] = v; }
 }
 
+
+// Attention gate (archs.py:138-144): y[p][c] = x[p][c] * sigmoid(g[p]), one gate value per pixel.
+__global__ __launch_bounds__(256) void pixel_gate_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g, int ldg,
+                                                             long long P, int C, float* __restrict__ y, int ldy) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, P * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    const float s = 1.f / (1.f + __expf(-g[p * ldg]));
+    *(f32x4*)(y + p * ldy + 4 * cq) = *(const f32x4*)(x + p * ldx + 4 * cq) * s;
+  }
+}
+// dx = dy * s;  dg[p] = (sum_c dy[p][c] * x[p][c]) * s * (1 - s).  16 lanes per pixel, fixed shuffle tree.
+__global__ __launch_bounds__(256) void pixel_gate_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g, int ldg,
+                                                             const float* __restrict__ dy, int lddy, long long P, int C,
+                                                             float* __restrict__ dx, int lddx, float* __restrict__ dg, int lddg) {
+  const int CQ = C / 4;
+  const int sub = threadIdx.x & 15;
+  const long long groups = ((long long)gridDim.x * 256) >> 4;
+  const long long iters = (P + groups - 1) / groups;
+  for (long long it = 0; it < iters; ++it) {
+    const long long p = (((long long)blockIdx.x * 256 + threadIdx.x) >> 4) + it * groups;
+    const bool ok = p < P;
+    float s = 0.f, acc = 0.f;
+    if (ok) {
+      s = 1.f / (1.f + __expf(-g[p * ldg]));
+      for (int cq = sub; cq < CQ; cq += 16) {
+        const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq), dv = *(const f32x4*)(dy + p * lddy + 4 * cq);
+        acc += (dv[0] * xv[0] + dv[1] * xv[1]) + (dv[2] * xv[2] + dv[3] * xv[3]);
+        *(f32x4*)(dx + p * lddx + 4 * cq) = dv * s;
+      }
+    }
+    acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
+    if (ok && sub == 0) *(f32x4*)(dg + p * lddg) = f32x4{acc * s * (1.f - s), 0.f, 0.f, 0.f};
+  }
+}
 }  // namespace
 
 extern "C" int ssg_spade_modulate_fwd_f32(const float* x, int ldx, const float* gb, int ldgb, int64_t P, int C, float* y, int ldy, void* stream) {
@@ -219,6 +254,22 @@ extern "C" int ssg_clamp_multi_f32(const void* const* ptrs, const int64_t* sizes
 extern "C" int ssg_copy_channels_f32(const float* src, int ldsrc, int64_t P, int C, float* dst, int lddst, void* stream) {
   SSG_REQUIRE(src && dst && P > 0 && C > 0 && C % 4 == 0 && ldsrc % 4 == 0 && lddst % 4 == 0, SSG_EINVAL, "copy_channels: bad args");
   hipLaunchKernelGGL(copy_channels_kernel, dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, ldsrc, (long long)P, C, dst, lddst);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+extern "C" int ssg_pixel_gate_fwd_f32(const float* x, int ldx, const float* g, int ldg, int64_t P, int C, float* y, int ldy, void* stream) {
+  SSG_REQUIRE(x && g && y && P > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, SSG_EINVAL, "pixel_gate_fwd: bad args");
+  hipLaunchKernelGGL(pixel_gate_fwd_kernel, dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, g, ldg, (long long)P, C, y, ldy);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_pixel_gate_bwd_f32(const float* x, int ldx, const float* g, int ldg, const float* dy, int lddy, int64_t P, int C,
+                                      float* dx, int lddx, float* dg, int lddg, void* stream) {
+  SSG_REQUIRE(x && g && dy && dx && dg && P > 0 && C > 0 && C % 4 == 0, SSG_EINVAL, "pixel_gate_bwd: bad args");
+  SSG_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddg % 4 == 0 && ssg_aligned16(dg), SSG_EALIGN, "pixel_gate_bwd: strides");
+  hipLaunchKernelGGL(pixel_gate_bwd_kernel, dim3(elem_grid(P * 16)), dim3(256), 0, (hipStream_t)stream, x, ldx, g, ldg, dy, lddy, (long long)P, C,
+                     dx, lddx, dg, lddg);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

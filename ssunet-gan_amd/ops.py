@@ -504,23 +504,54 @@ def _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, want_dres, w
     return dx, dres, dwb[0], dwb[1]
 
 
+def _relabel(t, c):
+    """The same NHWC-with-stride memory seen with `c` logical channels (c <= pixel stride); a base tensor, not a view."""
+    n, _, h, w = t.shape
+    return torch.empty(0, device=t.device, dtype=t.dtype).set_(t.untyped_storage(), t.storage_offset(), (n, c, h, w), t.stride())
+
+
 class _BatchNormAct(torch.autograd.Function):
+    """Channel counts that are not multiples of 4 (the 1-channel psi BatchNorm of Attention_block, archs.py:128-132)
+    run on the padded lanes too: zero data with zero weight/bias stays zero."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group):
         x = to_nhwc(x)
         res = to_nhwc(res) if res is not None else None
-        y, stats, world = _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group)
+        c = x.shape[1]
+        c4 = pad4(c)
+        if c4 != c:
+            x = _relabel(x, c4)
+            res = _relabel(res, c4) if res is not None else None
+            wp = torch.nn.functional.pad(weight.detach(), (0, c4 - c)); bp = torch.nn.functional.pad(bias.detach(), (0, c4 - c))
+            rm = torch.nn.functional.pad(running_mean, (0, c4 - c)) if running_mean is not None else None
+            rv = torch.nn.functional.pad(running_var, (0, c4 - c), value=1.0) if running_var is not None else None
+            y, stats, world = _bn_fwd_impl(x, wp, bp, rm, rv, res, eps, momentum, act, slope, var_mode, group)
+            if running_mean is not None:
+                running_mean.copy_(rm[:c])
+            if running_var is not None:
+                running_var.copy_(rv[:c])
+            weight = wp
+        else:
+            y, stats, world = _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, weight, stats)
-        ctx.cfg = (act, slope, group, world, res is not None)
-        return y
+        ctx.cfg = (act, slope, group, world, res is not None, c)
+        return _relabel(y, c) if c4 != c else y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, y, weight, stats = ctx.saved_tensors
-        act, slope, group, world, has_res = ctx.cfg
+        act, slope, group, world, has_res, c = ctx.cfg
         dy = to_nhwc(dy)
+        c4 = x.shape[1]
+        if c4 != c:
+            dy = _relabel(dy, c4)
         dx, dres, dw, db = _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, has_res and ctx.needs_input_grad[5])
+        if c4 != c:
+            dx = _relabel(dx, c)
+            dres = _relabel(dres, c) if dres is not None else None
+            dw, db = dw[:c].clone(), db[:c].clone()
         return dx, dw, db, None, None, dres, None, None, None, None, None, None
 
 
@@ -562,6 +593,12 @@ def batch_norm_act(x, bn, res=None, act=ACT_NONE, slope=0.0, group=None, var_mod
         shift = -bn.running_mean * scale
         if bn.bias is not None:
             shift = shift + bn.bias
+        c = scale.numel()
+        if c % 4:                                           # 1-channel psi batch norm: run the padded lanes with scale = shift = 0
+            scale = torch.nn.functional.pad(scale, (0, pad4(c) - c)); shift = torch.nn.functional.pad(shift, (0, pad4(c) - c))
+            y = _AffineAct.apply(_relabel(to_nhwc(x), pad4(c)), scale.contiguous(), shift.contiguous(),
+                                 _relabel(to_nhwc(res), pad4(c)) if res is not None else None, int(act), float(slope))
+            return _relabel(y, c)
     return _AffineAct.apply(x, scale.contiguous(), shift.contiguous(), res, int(act), float(slope))
 
 
@@ -949,6 +986,37 @@ class _Mul(torch.autograd.Function):
 def mul(a, b):
     _lib.require_gpu(a)
     return _Mul.apply(a, b)
+
+
+class _PixelGate(torch.autograd.Function):
+    """x * sigmoid(g) with a one-channel gate g broadcast over the channels (Attention_block, archs.py:138-144)."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        x = to_nhwc(x); g = to_nhwc(g)
+        n, c, h, w = x.shape
+        if tuple(g.shape) != (n, 1, h, w):
+            raise ValueError('pixel_gate: gate must be [N,1,H,W], got %s' % (tuple(g.shape),))
+        y = new_nhwc(n, c, h, w, x.device)
+        call('ssg_pixel_gate_fwd_f32', ptr(x), _ld(x), ptr(g), _ld(g), n * h * w, pad4(c), ptr(y), _ld(y), stream_ptr())
+        ctx.save_for_backward(x, g)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        n, c, h, w = x.shape
+        dx = new_nhwc(n, c, h, w, x.device); dg = new_nhwc(n, 1, h, w, x.device)
+        call('ssg_pixel_gate_bwd_f32', ptr(x), _ld(x), ptr(g), _ld(g), ptr(dy), _ld(dy), n * h * w, pad4(c),
+             ptr(dx), _ld(dx), ptr(dg), _ld(dg), stream_ptr())
+        return dx, dg
+
+
+def pixel_gate(x, g):
+    _lib.require_gpu(x)
+    return _PixelGate.apply(x, g)
 
 
 class _GlobalAvgPool(torch.autograd.Function):

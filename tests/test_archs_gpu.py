@@ -1,5 +1,5 @@
 """The other exported generators (UNet, NestedUNet +- deep supervision, SSUNet,
-UNet_ori, UNet_B_SS, UNet_R_SS) on the HIP path vs golden vectors from the reference's archs.py."""
+UNet_ori, UNet_B_SS, UNet_R_SS, AttUNet) on the HIP path vs golden vectors from the reference's archs.py."""
 import os
 
 import numpy as np
@@ -11,7 +11,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 CASES = [('UNet', False), ('NestedUNet', False), ('NestedUNet', True), ('SSUNet', False), ('UNet_ori', False),
-         ('UNet_B_SS', False), ('UNet_R_SS', False)]
+         ('UNet_B_SS', False), ('UNet_R_SS', False), ('AttUNet', False)]
 
 
 @pytest.mark.parametrize('name,ds', CASES)

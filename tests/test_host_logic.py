@@ -50,7 +50,7 @@ def test_no_cpu_fallback(pkg):
     with pytest.raises(RuntimeError):
         pkg.losses.BCEDiceLoss()(torch.zeros(1, 3, 4, 4), torch.zeros(1, 3, 4, 4))
     with pytest.raises(NotImplementedError):
-        pkg.models_seg_gan.Generator(dict(arch='AttUNet', num_classes=3, input_channels=3, deep_supervision=False))
+        pkg.models_seg_gan.Generator(dict(arch='NoSuchArch', num_classes=3, input_channels=3, deep_supervision=False))
 
 
 def test_missing_library_fails_loudly(pkg, monkeypatch):

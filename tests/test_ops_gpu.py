@@ -144,7 +144,8 @@ def test_conv2d_concat_and_act(pkg, dev):
 
 
 @pytest.mark.parametrize('shape,act,res', [((2, 16, 10, 12), 'relu', True), ((3, 64, 8, 8), 'lrelu', False),
-                                           ((1, 384, 4, 4), 'none', False), ((2, 8, 33, 17), 'relu', False)])
+                                           ((1, 384, 4, 4), 'none', False), ((2, 8, 33, 17), 'relu', False),
+                                           ((3, 1, 9, 7), 'none', False), ((2, 3, 8, 8), 'relu', True)])
 def test_batch_norm_act(pkg, dev, shape, act, res):
     g = torch.Generator().manual_seed(5)
     n, c, h, w = shape
@@ -174,6 +175,22 @@ def test_batch_norm_act(pkg, dev, shape, act, res):
     assert int(bn_d.num_batches_tracked) == 1
     if res:
         _close(rd.grad, rref.grad, 1e-6, 1e-6, 'bn dres')
+
+
+def test_pixel_gate(pkg, dev):
+    """Attention gate x * sigmoid(psi) with a one-channel psi (Attention_block, archs.py:138-144)."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 40, 9, 11, generator=g); p = torch.randn(2, 1, 9, 11, generator=g)
+    xr = x.clone().requires_grad_(True); pr = p.clone().requires_grad_(True)
+    yr = xr * torch.sigmoid(pr)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xd = x.to(dev).requires_grad_(True); pd = p.to(dev).requires_grad_(True)
+    yd = pkg.ops.pixel_gate(xd, pd)
+    yd.backward(dy.to(dev))
+    _close(yd, yr, 1e-6, 1e-6, 'pixel gate')
+    _close(xd.grad, xr.grad, 1e-6, 1e-6, 'pixel gate dx')
+    _close(pd.grad, pr.grad, 1e-5, 1e-5, 'pixel gate dpsi')
 
 
 def test_pool_unpool(pkg, dev):
