@@ -24,10 +24,10 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-# 2*(3*208.625 + 9*24.631) GFLOP per image per step.  The discriminator's parameter gradients of the
-# G-step backward are dead in the reference (zeroed at train_seg_gan.py:225 before any use) and are not computed
-# unless SSG_KEEP_DEAD_D_GRADS=1 (ssunet-gan_amd/train_seg_gan.py): 8 instead of 9 discriminator passes EXECUTED.
-D_PASSES = 9 if os.environ.get('SSG_KEEP_DEAD_D_GRADS', '0') == '1' else 8
+# 2*(3*208.625 + 9*24.631) GFLOP per image per step.  With the opt-in SSG_ELIDE_DEAD_D_GRADS=1
+# (ssunet-gan_amd/train_seg_gan.py: the discriminator parameter gradients of the G-step backward, which the reference
+# zeroes unread at train_seg_gan.py:225, are not computed) 8 instead of 9 discriminator passes are EXECUTED.
+D_PASSES = 8 if os.environ.get('SSG_ELIDE_DEAD_D_GRADS', '0') == '1' else 9
 FLOP_PER_IMG_512 = 2 * (3 * 208.625 + D_PASSES * 24.631) * 1e9
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 # HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
