@@ -111,13 +111,8 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // tap t reads window pixel (dy+1)*WW + (px + dx + 1): float offset of tap t for pixel 0
-  int toff[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
-    toff[t] = (((tb & 7) - 2 + 1) * WW + ((tb >> 3) - 2) + 1) * CB;
-  }
+  // tap t = (dy+1)*3 + (dx+1) (checked on the host) reads window pixel (dy+1)*WW + (px + dx + 1): the LDS
+  // offsets are compile-time constants, so pairs of reads fuse into ds_read2 and need no address arithmetic
 
   if (nsteps > 0) issue(0);
   if (nsteps > 1) issue(1);
@@ -135,7 +130,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgArgs a) {
       const float fb = Bb[2 * kk * BN];
       float fa[9];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) fa[t] = Aw[toff[t] + 2 * kk * CB];
+      for (int t = 0; t < 9; ++t) fa[t] = Aw[((t / 3) * WW + (t % 3) + 2 * kk) * CB];
 #pragma unroll
       for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb, acc[t], 0, 0, 0);
     }
@@ -172,8 +167,8 @@ bool ssg_wgrad_halo_ok(const ssg_wgrad_desc* d, int variant) {
   if (d->ntaps != 9 || d->in_sy != 1 || d->in_sx != 1 || d->GH != d->H || d->GW != d->W) return false;
   unsigned seen = 0;
   for (int t = 0; t < 9; ++t) {
-    if (d->dy[t] < -1 || d->dy[t] > 1 || d->dx[t] < -1 || d->dx[t] > 1) return false;
-    seen |= 1u << ((d->dy[t] + 1) * 3 + d->dx[t] + 1);
+    if (d->dy[t] != t / 3 - 1 || d->dx[t] != t % 3 - 1) return false;      // row-major window order
+    seen |= 1u << t;
   }
   if (seen != 0x1ffu) return false;
   const int cb = ssg_wgrad_halo_cb(variant);
