@@ -23,3 +23,20 @@ tot = sum(a[1] for a in agg.values())
 print('total mfma ms %.1f' % tot)
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     print('%-72s x%-3d %7.2f ms %5.1f%%  %6.1f TF' % (k, a[2], a[1], 100*a[1]/tot, a[0]/a[1]/1e9))
+
+# algorithmic HBM bytes per launch of each kernel (input + output + weights, fp32), to set against the PMC traffic
+import re
+per_kernel = {}
+for k, a in agg.items():
+    m = re.match(r'(\S+) n(\d+) (\d+)x(\d+) cin(\d+) cout(\d+) (?:taps|k)(\d+)', k)
+    if not m:
+        continue
+    name, n, gh, gw, cin, cout, taps = m.group(1), *map(int, m.groups()[1:])
+    if name.startswith('wgrad'):
+        taps = taps * taps                      # 'k3' -> 9 taps
+    byts = 4.0 * (n * gh * gw * (cin + cout) + cin * cout * taps)
+    p = per_kernel.setdefault(name, [0.0, 0])
+    p[0] += byts * a[2]; p[1] += a[2]
+print('\nalgorithmic bytes per launch (in + out + weights):')
+for name, (b, c) in sorted(per_kernel.items(), key=lambda kv: -kv[1][0]):
+    print('%-40s launches %4d  avg %8.1f MB' % (name, c, b / c / 1e6))
