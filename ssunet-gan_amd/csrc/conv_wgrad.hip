@@ -207,7 +207,8 @@ Plan make_plan(const ssg_wgrad_desc* d) {
     p.mt = Cin / ssg_wgrad_halo_cb(p.variant);
     steps = (long long)d->N * d->GH * ((d->GW + BKP - 1) / BKP);
   }
-  long long want = 2048 / ((long long)p.mt * p.nt);      // ~8 workgroups per CU overall
+  static const int wgs = [] { const char* e = getenv("SSG_WGRAD_WGS"); return e ? atoi(e) : 1024; }();
+  long long want = wgs / ((long long)p.mt * p.nt);       // ~4 workgroups per CU overall (2048: +0.4 % slab traffic time)
   if (want < 1) want = 1;
   long long maxs = steps / 16;                           // at least 16 K-steps (256 pixels) per split
   if (maxs < 1) maxs = 1;

@@ -21,7 +21,7 @@ for label, fl, e0, e1 in S.ops.PROFILE:
     a = agg.setdefault(label, [0, 0, 0]); a[0] += fl; a[1] += e0.elapsed_time(e1); a[2] += 1
 tot = sum(a[1] for a in agg.values())
 print('total mfma ms %.1f' % tot)
-for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print('%-72s x%-3d %7.2f ms %5.1f%%  %6.1f TF' % (k, a[2], a[1], 100*a[1]/tot, a[0]/a[1]/1e9))
 
 # algorithmic HBM bytes per launch of each kernel (input + output + weights, fp32), to set against the PMC traffic
