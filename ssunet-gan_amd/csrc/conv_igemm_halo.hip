@@ -250,6 +250,17 @@ bool ssg_conv_halo_ok(const ConvArgs& a) {
 }
 
 int ssg_conv_igemm_halo_launch(const ConvArgs& a, int variant, hipStream_t st) {
-  if (variant == 0) return launch<128, 128, 2, 2>(a, st);
-  return launch<256, 64, 4, 1>(a, st);
+  switch (ssg_conv_halo_variant(a, variant)) {
+    case 0: return launch<128, 128, 2, 2>(a, st);
+    case 2: return launch<128, 64, 2, 2>(a, st);
+    default: return launch<256, 64, 4, 1>(a, st);
+  }
+}
+
+// 0 = <128,128> (Cout > 64), 1 = <256,64>, 2 = <128,64>: for Cout <= 64 with a short K loop (Cin <= 128: 36-72
+// steps per tile) four small workgroups per CU hide each other's prologue and epilogue better than two big ones
+// (measured at 16x512^2: Cin=64 108 -> 122 TFLOP/s, Cin=128 123 -> 128, Cin=192 132 -> 130)
+int ssg_conv_halo_variant(const ConvArgs& a, int variant) {
+  if (variant == 0) return 0;
+  return (a.C1 + a.C2) <= 128 ? 2 : 1;
 }
