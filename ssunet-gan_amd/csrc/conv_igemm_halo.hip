@@ -261,6 +261,7 @@ int ssg_conv_igemm_halo_launch(const ConvArgs& a, int variant, hipStream_t st) {
 // steps per tile) four small workgroups per CU hide each other's prologue and epilogue better than two big ones
 // (measured at 16x512^2: Cin=64 108 -> 122 TFLOP/s, Cin=128 123 -> 128, Cin=192 132 -> 130)
 int ssg_conv_halo_variant(const ConvArgs& a, int variant) {
-  if (variant == 0) return 0;
+  // Cout > 64 with Cin = 64 on the largest grids also prefers two <128,64> column tiles (110 -> 120 at 16x512^2)
+  if (variant == 0) return ((a.C1 + a.C2) <= 64 && (long long)a.N * a.GH * a.GW >= (1ll << 22)) ? 2 : 0;
   return (a.C1 + a.C2) <= 128 ? 2 : 1;
 }
