@@ -262,6 +262,10 @@ int ssg_conv_igemm_halo_launch(const ConvArgs& a, int variant, hipStream_t st) {
 // (measured at 16x512^2: Cin=64 108 -> 122 TFLOP/s, Cin=128 123 -> 128, Cin=192 132 -> 130)
 int ssg_conv_halo_variant(const ConvArgs& a, int variant) {
   // Cout > 64 with Cin = 64 on the largest grids also prefers two <128,64> column tiles (110 -> 120 at 16x512^2)
+  if (variant == 0) {            // fewer than 3 workgroups per CU with 128x128 tiles: halve the tile (16x16 level)
+    const long long wgs = (long long)a.N * ((a.GH + 3) / 4) * ((a.GW + 31) / 32) * ((a.Cout + 127) / 128);
+    if (wgs < 768) return 2;
+  }
   if (variant == 0) return ((a.C1 + a.C2) <= 64 && (long long)a.N * a.GH * a.GW >= (1ll << 22)) ? 2 : 0;
   return (a.C1 + a.C2) <= 128 ? 2 : 1;
 }
