@@ -68,10 +68,11 @@ KERNEL_CASES = [
     (2, 3, 64, 37, 45, 3, 1, ('thin4_cin_kernel', 'thin4_cout_kernel', 'wgrad4_kernel<thin_cin>')),
     (1, 128, 4, 19, 23, 3, 1, ('thin4_cout_kernel', 'thin4_cin_kernel', 'wgrad4_kernel<thin_cout>')),
     (2, 64, 1, 16, 20, 1, 0, ('thin4_cout_kernel', 'thin4_cin_kernel', 'wgrad4_kernel<thin_cout>')),
-    (2, 64, 128, 37, 45, 3, 1, ('conv_igemm_halo_kernel<128,128>', 'conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<32,128>')),
-    (1, 128, 64, 21, 70, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'conv_igemm_halo_kernel<128,128>', 'wgrad_halo_kernel<64,64>')),
-    (1, 192, 64, 17, 40, 3, 1, ('conv_igemm_halo_kernel<256,64>', 'conv_igemm_halo_kernel<128,128>', 'wgrad_halo_kernel<64,64>')),
-    (1, 96, 64, 9, 33, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'conv_igemm_halo_kernel<128,128>', 'wgrad_dma_kernel<128,64>')),
+    (2, 64, 128, 37, 45, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<32,128>')),
+    (4, 32, 128, 128, 192, 3, 1, ('conv_igemm_halo_kernel<128,128>', 'conv_igemm_kernel<256,32>', 'wgrad_halo_kernel<32,128>')),
+    (1, 128, 64, 21, 70, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<64,64>')),
+    (1, 192, 64, 17, 40, 3, 1, ('conv_igemm_halo_kernel<256,64>', 'conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<64,64>')),
+    (1, 96, 64, 9, 33, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_dma_kernel<128,64>')),
     (2, 48, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,128>', 'conv_igemm_dma_kernel<256,64>', 'wgrad_dma_kernel<128,128>')),
 ]
 
@@ -122,7 +123,7 @@ def test_conv2d_concat_halo(pkg, dev):
         labels = [rec[0] for rec in pkg.ops.PROFILE]
     finally:
         pkg.ops.PROFILE = None
-    assert 'conv_igemm_halo_kernel<128,128>' in labels and 'wgrad_halo_kernel<32,128>' in labels, labels
+    assert 'conv_igemm_halo_kernel<128,64>' in labels and 'wgrad_halo_kernel<32,128>' in labels, labels
     _close(yd, yr, 1e-5, 7e-5, 'concat halo conv')
     for a, b, nm in zip(d, r, ('dx1', 'dx2', 'dw')):
         _close(a.grad, b.grad, 2e-5, 7e-5, nm)
