@@ -167,13 +167,17 @@ int ssg_bn_apply_f32(const float* x, int64_t P, int C, int ld, const float* scal
                      const float* res, int ldr, int act, float slope, float* y, int ldy, void* stream);
 /* backward: g = dy masked by the activation (y>0 ? 1 : slope), dres = g (if wanted);
  *   stage 1: sums[0:C] = sum g, sums[C:2C] = sum g*xhat   (fp64; all-reduced for sync-BN)
- *   apply  : dx = scale*(g - sums0/count - xhat*sums1/count); dweight = sums1, dbias = sums0 */
+ *   apply  : dx = scale*(g - sums0/count - xhat*sums1/count); dweight = sums1, dbias = sums0
+ * The activation mask comes from the saved output y, or -- y = NULL, for a forward WITHOUT residual -- is
+ * recomputed from x with the (scale, shift) the forward used (one tensor read less per kernel). */
 int ssg_bn_bwd_reduce_f32(const float* x, const float* y, const float* dy, int64_t P, int C,
                           int ldx, int ldy, int lddy, const float* mean, const float* invstd,
+                          const float* scale, const float* shift,
                           int act, float slope, double* sums, void* ws, void* stream);
 int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float* dy, int64_t P, int C,
                          int ldx, int ldy, int lddy, const float* mean, const float* invstd,
-                         const float* weight, const double* sums, double count, int act, float slope,
+                         const float* weight, const float* scale, const float* shift,
+                         const double* sums, double count, int act, float slope,
                          float* dx, int lddx, float* dres, int lddres,
                          float* dweight, float* dbias, void* stream);
 /* eval-mode / generic per-channel affine: y = x*scale + shift -> act (also used for bias+act) */

@@ -49,7 +49,7 @@ class _BasicBlockFn(torch.autograd.Function):
         dc2, g, dg2, db2 = _bn_bwd_impl(c2, out, dout, g2, st2, ACT_RELU, 0.0, group, world, want_dres=True)
         dw2 = _conv_wgrad_impl(y1, None, dc2, w2.shape, 1, 1)
         dy1 = _conv_dgrad_impl(dc2, w2, 1, 1, y1.shape[2], y1.shape[3], 0, y1.shape[1])
-        dc1, _, dg1, db1 = _bn_bwd_impl(c1, y1, dy1, g1, st1, ACT_RELU, 0.0, group, world, want_dres=False)
+        dc1, _, dg1, db1 = _bn_bwd_impl(c1, y1, dy1, g1, st1, ACT_RELU, 0.0, group, world, want_dres=False, had_res=False)
         dw1 = _conv_wgrad_impl(x1, x2, dc1, w1.shape, stride, 1)
         dwsc = _conv_wgrad_impl(x1, x2, g, wsc.shape, stride, 0) if wsc is not None else None
         dx1 = dx2 = None

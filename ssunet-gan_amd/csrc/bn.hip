@@ -36,7 +36,8 @@ __host__ RedGeom red_geom(long long P, int C) {
 template <int MODE>
 __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, long long P, int C,
-    int ldx, int ldy, int lddy, const float* __restrict__ mean, const float* __restrict__ invstd, int act, float slope,
+    int ldx, int ldy, int lddy, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope,
     int TQ, int PR, long long rows_per_part, double* __restrict__ part /* [parts][2][Cq4] */) {
   __shared__ double red[2][RED_BLOCK][4];
   const int tid = threadIdx.x;
@@ -49,10 +50,13 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
   // fp64 accumulators: var = E[x^2] - mean^2 cancels catastrophically in fp32 for channels whose
   // variance is far below mean^2 (deep layers with few pixels); x*x is exact in fp64.
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+  f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
   if (MODE == 1 && cok) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const int c = 4 * cq + e; if (c < C) { mu[e] = mean[c]; is[e] = invstd[c]; } }
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * cq + e;
+      if (c < C) { mu[e] = mean[c]; is[e] = invstd[c]; if (!y && scale) { sc[e] = scale[c]; sh[e] = shift[c]; } }
+    }
   }
   if (cok) {
     for (long long p = p0 + pr; p < p1; p += PR) {
@@ -66,7 +70,9 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
       } else {
         f32x4 g = *(const f32x4*)(dy + p * lddy + 4 * cq);
         if (act != SSG_ACT_NONE) {
-          const f32x4 yv = *(const f32x4*)(y + p * ldy + 4 * cq);
+          // activation mask: from the saved output, or -- when the forward had no residual -- recomputed with
+          // the forward's own expression x*scale + shift (same fp32 fma, same inputs: bitwise the same sign)
+          const f32x4 yv = y ? *(const f32x4*)(y + p * ldy + 4 * cq) : xv * sc + sh;
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) g[e] *= (act == SSG_ACT_RELU ? 0.f : slope);
         }
@@ -162,6 +168,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, long long P, int C, int ldx,
     int ldy, int lddy, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ weight,
+    const float* __restrict__ scale, const float* __restrict__ shift,
     const double* __restrict__ sums, double count, int act, float slope, float* __restrict__ dx, int lddx,
     float* __restrict__ dres, int lddres, float* __restrict__ dweight, float* __restrict__ dbias) {
   const int CQ = C / 4;
@@ -184,14 +191,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long p = i / CQ; const int cq = (int)(i - p * CQ);
     f32x4 g = *(const f32x4*)(dy + p * lddy + 4 * cq);
+    const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
     if (act != SSG_ACT_NONE) {
-      const f32x4 yv = *(const f32x4*)(y + p * ldy + 4 * cq);
+      const f32x4 yv = y ? *(const f32x4*)(y + p * ldy + 4 * cq)
+                         : xv * *(const f32x4*)(scale + 4 * cq) + *(const f32x4*)(shift + 4 * cq);
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) g[e] *= (act == SSG_ACT_RELU ? 0.f : slope);
     }
     if (dres) *(f32x4*)(dres + p * lddres + 4 * cq) = g;
     if (dx) {
-      const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
       f32x4 o;
       // fp64 arithmetic, as ATen's CPU batch-norm backward (accscalar = double for float tensors):
       // g - mean(g) - xhat*mean(g*xhat) cancels heavily, and an fp32-rounded per-channel constant
@@ -217,13 +225,14 @@ int elem_grid(long long total) {
 
 template <int MODE>
 int run_reduce(const float* x, const float* y, const float* dy, long long P, int C, int ldx, int ldy, int lddy,
+               const float* scale, const float* shift,
                const float* mean, const float* invstd, int act, float slope, double* sums, float* fsum, void* ws,
                hipStream_t st) {
   const RedGeom g = red_geom(P, C);
   const int C4 = 4 * ((C + 3) / 4);
   double* part = (double*)ws;
   hipLaunchKernelGGL((col_reduce_kernel<MODE>), dim3((unsigned)g.parts, (unsigned)g.groups), dim3(RED_BLOCK), 0, st, x, y, dy,
-                     P, C, ldx, ldy, lddy, mean, invstd, act, slope, g.TQ, g.PR, g.rows_per_part, part);
+                     P, C, ldx, ldy, lddy, mean, invstd, scale, shift, act, slope, g.TQ, g.PR, g.rows_per_part, part);
   SSG_LAUNCH_CHECK();
   hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C4, sums, fsum);
   SSG_LAUNCH_CHECK();
@@ -240,13 +249,13 @@ extern "C" int64_t ssg_bn_workspace_bytes(int64_t P, int C) {
 extern "C" int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, void* ws, void* stream) {
   SSG_REQUIRE(x && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_stats: bad args");
   SSG_REQUIRE(ld % 4 == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN, "bn_stats: alignment");
-  return run_reduce<0>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, 0, 0.f, sums, nullptr, ws, (hipStream_t)stream);
+  return run_reduce<0>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, sums, nullptr, ws, (hipStream_t)stream);
 }
 
 extern "C" int ssg_channel_sum_f32(const float* x, int64_t P, int C, int ld, float* out, void* ws, void* stream) {
   SSG_REQUIRE(x && out && ws && P > 0 && C > 0, SSG_EINVAL, "channel_sum: bad args");
   SSG_REQUIRE(ld % 4 == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN, "channel_sum: alignment");
-  return run_reduce<2>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, 0, 0.f, nullptr, out, ws, (hipStream_t)stream);
+  return run_reduce<2>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, nullptr, out, ws, (hipStream_t)stream);
 }
 
 extern "C" int ssg_bn_finalize_f32(const double* sums, double count, int C, const float* weight, const float* bias,
@@ -270,20 +279,21 @@ extern "C" int ssg_bn_apply_f32(const float* x, int64_t P, int C, int ld, const 
 }
 
 extern "C" int ssg_bn_bwd_reduce_f32(const float* x, const float* y, const float* dy, int64_t P, int C, int ldx, int ldy,
-                                     int lddy, const float* mean, const float* invstd, int act, float slope, double* sums,
-                                     void* ws, void* stream) {
+                                     int lddy, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                     int act, float slope, double* sums, void* ws, void* stream) {
   SSG_REQUIRE(x && dy && mean && invstd && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_bwd_reduce: bad args");
-  SSG_REQUIRE(act == SSG_ACT_NONE || y, SSG_EINVAL, "bn_bwd_reduce: activation mask needs y");
+  SSG_REQUIRE(act == SSG_ACT_NONE || y || (scale && shift), SSG_EINVAL, "bn_bwd_reduce: activation mask needs y or (scale, shift)");
   SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_reduce: alignment");
-  return run_reduce<1>(x, y, dy, P, C, ldx, ldy, lddy, mean, invstd, act, slope, sums, nullptr, ws, (hipStream_t)stream);
+  return run_reduce<1>(x, y, dy, P, C, ldx, ldy, lddy, scale, shift, mean, invstd, act, slope, sums, nullptr, ws, (hipStream_t)stream);
 }
 
 extern "C" int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float* dy, int64_t P, int C, int ldx, int ldy,
-                                    int lddy, const float* mean, const float* invstd, const float* weight, const double* sums,
+                                    int lddy, const float* mean, const float* invstd, const float* weight,
+                                    const float* scale, const float* shift, const double* sums,
                                     double count, int act, float slope, float* dx, int lddx, float* dres, int lddres,
                                     float* dweight, float* dbias, void* stream) {
   SSG_REQUIRE(x && dy && mean && invstd && sums && P > 0 && C > 0 && count > 0, SSG_EINVAL, "bn_bwd_apply: bad args");
-  SSG_REQUIRE(act == SSG_ACT_NONE || y, SSG_EINVAL, "bn_bwd_apply: activation mask needs y");
+  SSG_REQUIRE(act == SSG_ACT_NONE || y || (scale && shift), SSG_EINVAL, "bn_bwd_apply: activation mask needs y or (scale, shift)");
   SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_apply: alignment");
   SSG_REQUIRE(C <= 4096, SSG_EINVAL, "bn_bwd_apply: C > 4096");
   if ((size_t)5 * C * sizeof(double) > 48 * 1024) {
@@ -291,8 +301,8 @@ extern "C" int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float*
     if (e != hipSuccess) { ssg_set_error("bn_bwd_apply: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), (size_t)5 * C * sizeof(double), (hipStream_t)stream, x, y, dy,
-                     P, C, ldx, ldy, lddy, mean, invstd, weight, sums, count, act, slope, dx, lddx, dres, lddres, dweight,
-                     dbias);
+                     P, C, ldx, ldy, lddy, mean, invstd, weight, scale, shift, sums, count, act, slope, dx, lddx, dres, lddres,
+                     dweight, dbias);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

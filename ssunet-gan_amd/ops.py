@@ -479,15 +479,18 @@ def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum,
     return y, stats, world
 
 
-def _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, want_dres, want_dx=True):
-    """Returns (dx, dres, dweight, dbias).  y is only needed when act != none (activation mask)."""
+def _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, want_dres, want_dx=True, had_res=True):
+    """Returns (dx, dres, dweight, dbias).  The activation mask is read from y, or -- when the forward had no
+    residual (`had_res=False`) -- recomputed from x with the forward's (scale, shift): y is then not read."""
     n, c, h, w = x.shape
     p = n * h * w
     dev = x.device
+    if act == ACT_NONE or not had_res:
+        y = None
     ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
     sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
     call('ssg_bn_bwd_reduce_f32', ptr(x), ptr(y), ptr(dy), p, c, _ld(x), _ld(y) if y is not None else 0, _ld(dy),
-         ptr(stats[0]), ptr(stats[1]), act, slope, ptr(sums), ptr(ws), stream_ptr())
+         ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), act, slope, ptr(sums), ptr(ws), stream_ptr())
     # local (un-reduced) sums are this rank's weight/bias gradients; data-parallel all-reduces them later
     synced = group is not None and world > 1
     local = sums.clone() if synced else sums
@@ -496,7 +499,7 @@ def _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, want_dres, w
     dx = new_nhwc(n, c, h, w, dev) if want_dx else None
     dres = new_nhwc(n, c, h, w, dev) if want_dres else None
     call('ssg_bn_bwd_apply_f32', ptr(x), ptr(y), ptr(dy), p, c, _ld(x), _ld(y) if y is not None else 0, _ld(dy),
-         ptr(stats[0]), ptr(stats[1]), ptr(weight), ptr(sums), float(p * world), act, slope,
+         ptr(stats[0]), ptr(stats[1]), ptr(weight), ptr(stats[2]), ptr(stats[3]), ptr(sums), float(p * world), act, slope,
          ptr(dx), _ld(dx) if dx is not None else 0, ptr(dres), _ld(dres) if dres is not None else 0,
          ptr(dwb[0]), ptr(dwb[1]), stream_ptr())
     if synced:
@@ -534,7 +537,7 @@ class _BatchNormAct(torch.autograd.Function):
             weight = wp
         else:
             y, stats, world = _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group)
-        ctx.save_for_backward(x, y if act != ACT_NONE else None, weight, stats)
+        ctx.save_for_backward(x, y if (act != ACT_NONE and res is not None) else None, weight, stats)   # no residual: mask is recomputed
         ctx.cfg = (act, slope, group, world, res is not None, c)
         return _relabel(y, c) if c4 != c else y
 
@@ -547,7 +550,8 @@ class _BatchNormAct(torch.autograd.Function):
         c4 = x.shape[1]
         if c4 != c:
             dy = _relabel(dy, c4)
-        dx, dres, dw, db = _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, has_res and ctx.needs_input_grad[5])
+        dx, dres, dw, db = _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, has_res and ctx.needs_input_grad[5],
+                                        had_res=has_res)
         if c4 != c:
             dx = _relabel(dx, c)
             dres = _relabel(dres, c) if dres is not None else None
