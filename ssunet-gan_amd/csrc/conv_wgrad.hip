@@ -156,8 +156,16 @@ __global__ __launch_bounds__(32 * ZL) void wgrad_reduce_kernel(const RedArgs a) 
   const long long idx = (long long)blockIdx.x * 32 + el;
   const long long tot = (long long)a.M * a.Cout;
   float s = 0.f;
-  if (idx < tot)
-    for (int z = zl; z < a.splits; z += ZL) s += a.ws[(size_t)z * tot + idx];
+  if (idx < tot) {
+    // four independent loads in flight per lane; the additions stay in slab order
+    int z = zl;
+    for (; z + 3 * ZL < a.splits; z += 4 * ZL) {
+      const float v0 = a.ws[(size_t)z * tot + idx], v1 = a.ws[(size_t)(z + ZL) * tot + idx];
+      const float v2 = a.ws[(size_t)(z + 2 * ZL) * tot + idx], v3 = a.ws[(size_t)(z + 3 * ZL) * tot + idx];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; z < a.splits; z += ZL) s += a.ws[(size_t)z * tot + idx];
+  }
   red[zl][el] = s;
   __syncthreads();
   if (zl != 0 || idx >= tot) return;
