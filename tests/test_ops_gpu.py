@@ -106,6 +106,47 @@ def test_conv2d_specialised_kernels(pkg, dev, case):
     _close(d[3].grad, ref[3].grad, 1e-6, 1e-6, 'residual grad')
 
 
+def _random_conv_cases(count=28, seed=2024):
+    rng = np.random.RandomState(seed)
+    cins = [3, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192]
+    couts = [1, 3, 4, 8, 16, 32, 40, 64, 96, 128, 160]
+    cases = []
+    for _ in range(count):
+        k = int(rng.choice([1, 3, 3]))
+        cases.append((int(rng.randint(1, 4)), int(rng.choice(cins)), int(rng.choice(couts)), int(rng.randint(3, 71)),
+                      int(rng.randint(3, 71)), k, bool(rng.randint(2)), bool(rng.randint(2))))
+    return cases
+
+
+@pytest.mark.parametrize('case', _random_conv_cases())
+def test_conv2d_random_shapes(pkg, dev, case):
+    """Seeded random (N, Cin, Cout, H, W, k, bias, residual): whatever kernel the dispatchers pick for a shape --
+    thin4 / wgrad4 / halo / DMA / register-staged, ragged tiles, images smaller than one tile -- must match torch."""
+    n, cin, cout, h, w, k, bias, res = case
+    g = torch.Generator().manual_seed(n * 1000003 + cin * 1009 + cout * 101 + h * 7 + w)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) if bias else None
+    rs = torch.randn(n, cout, h, w, generator=g) if res else None
+    ref = [t.clone().requires_grad_(True) if t is not None else None for t in (x, wt, b, rs)]
+    yr = F.conv2d(ref[0], ref[1], ref[2], 1, k // 2)
+    if res:
+        yr = yr + ref[3]
+    yr = F.relu(yr)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    d = [t.to(dev).requires_grad_(True) if t is not None else None for t in (x, wt, b, rs)]
+    yd = pkg.ops.conv2d(d[0], d[1], d[2], 1, k // 2, act=pkg._lib.ACT_RELU, res=d[3])
+    yd.backward(dy.to(dev))
+    _close(yd, yr, 1e-5, 2e-6 * math.sqrt(cin * k * k), 'fwd %s' % (case,))
+    _close(d[0].grad, ref[0].grad, 1e-5, 2e-6 * math.sqrt(cout * k * k), 'dgrad %s' % (case,))
+    _close(d[1].grad, ref[1].grad, 2e-5, 2e-6 * math.sqrt(n * h * w), 'wgrad %s' % (case,))
+    if bias:
+        _close(d[2].grad, ref[2].grad, 2e-5, 1e-5, 'bias grad %s' % (case,))
+    if res:
+        _close(d[3].grad, ref[3].grad, 1e-6, 1e-6, 'residual grad %s' % (case,))
+
+
 def test_conv2d_concat_halo(pkg, dev):
     """torch.cat absorbed by the second input pointer, on the halo kernels (forward, both input gradients, weight gradient)."""
     g = torch.Generator().manual_seed(31)
