@@ -5,7 +5,7 @@
 // thin-Cin  (in has 4 channels, any Cout):  A = w[co = co0 + lane][tap][c]  (36 registers per lane, loaded once),
 //     B = in[pixel j + tap][c] broadcast over b -> after 36 MFMAs lane 4b+j holds out[pixel j][co0 + 4b .. +3]:
 //     one 16-B store per lane, four complete 256-B pixel rows per wave.
-// thin-Cout (Cout <= 4, Cin % 64 == 0):     the 16 blocks split K: block b owns channels 4b..4b+3 of a 64-channel
+// thin-Cout (Cout <= 8, Cin % 64 == 0):     the 16 blocks split K: block b owns channels 4b..4b+3 of a 64-channel
 //     chunk.  A = w[co = i][tap][chunk*64 + 4b + e], B = in[pixel j + tap][chunk*64 + 4b + e] (one 16-B load per
 //     lane per tap, four complete 256-B rows per wave); the 16 partial sums per output are folded by a
 //     data-halving butterfly over the lane bits of b (fixed order -> bitwise reproducible).
@@ -132,8 +132,9 @@ __global__ __launch_bounds__(256) void thin4_cin_kernel(const T4Args a) {
   if (pend_ptr) *(f32x4*)pend_ptr = pend;
 }
 
-// ------------------------------------------------------------------ thin-Cout: Cout <= 4, C % 64 == 0
-template <int KS>
+// ------------------------------------------------------------------ thin-Cout: Cout <= 4*NG, C % 64 == 0
+// NG = 2 (Cout 5..8, e.g. the 128 -> 8 gamma/beta input gradients) runs two A-operand sets over the same loaded rows.
+template <int KS, int NG>
 __global__ __launch_bounds__(256) void thin4_cout_kernel(const T4Args a) {
   constexpr int R = KS / 2, NT = KS * KS, S = RH_COUT, RING = KS + 1;
   const int lane = threadIdx.x & 63, j = lane & 3, b = lane >> 2;
@@ -143,11 +144,15 @@ __global__ __launch_bounds__(256) void thin4_cout_kernel(const T4Args a) {
   const auto in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)(npix * (unsigned)a.ld * 4u), 0x00020000);
   const unsigned ldb = (unsigned)a.ld * 4u;
   const int nchunks = a.C >> 6;
-  const int co = j;                                  // A operand row: lane 4b+i supplies w[co = i]
-  // after the butterfly lane (b, j) owns outputs (row s = b >> 1, pixel j, channels 2*(b&1), +1)
+  // A operand row: lane 4b+i supplies w[co = 4g + i]
+  // after the butterfly lane (b, j) owns outputs (row s = b >> 1, pixel j, channels 4g + 2*(b&1), +1)
   const int my_s = b >> 1, my_c = 2 * (b & 1);
-  float bias0 = 0.f, bias1 = 0.f;
-  if (a.bias) { bias0 = my_c < a.Cout ? a.bias[my_c] : 0.f; bias1 = my_c + 1 < a.Cout ? a.bias[my_c + 1] : 0.f; }
+  float bias0[NG], bias1[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    bias0[g] = (a.bias && 4 * g + my_c < a.Cout) ? a.bias[4 * g + my_c] : 0.f;
+    bias1[g] = (a.bias && 4 * g + my_c + 1 < a.Cout) ? a.bias[4 * g + my_c + 1] : 0.f;
+  }
 
   for (int u = wg; u < a.total_units; u += a.waves_per_group) {
     const int xs = u % a.strips; const int r0 = u / a.strips;
@@ -161,17 +166,23 @@ __global__ __launch_bounds__(256) void thin4_cout_kernel(const T4Args a) {
       coloff[e] = (unsigned)ix < (unsigned)a.W ? (unsigned)ix * ldb + 16u * b : OOB;
     }
     const unsigned imgoff = (unsigned)(n * a.H) * (unsigned)a.W * ldb;
-    f32x4 acc[S];
+    f32x4 accg[NG][S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int s = 0; s < S; ++s) accg[g][s] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int ch = 0; ch < nchunks; ++ch) {
       const int c0 = ch * 64 + 4 * b;                // this lane's 4 reduced channels
-      f32x4 wv[NT];
+      f32x4 wv[NG][NT];
 #pragma unroll
       for (int p = 0; p < NT; ++p) {
         const int t = a.tapidx[KS == 3 ? p : 4];
         const int k = a.kmode == 0 ? (c0 >> 4) * a.ntaps * 16 + t * 16 + (c0 & 15) : t * a.C + c0;
-        wv[p] = (co < a.Cout && t >= 0) ? *(const f32x4*)(a.w + (size_t)co * a.Kp + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int co = 4 * g + j;
+          wv[g][p] = (co < a.Cout && t >= 0) ? *(const f32x4*)(a.w + (size_t)co * a.Kp + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
       auto load_row = [&](f32x4* dst, int iy) {
         const bool rok = (unsigned)iy < (unsigned)a.H;
@@ -191,9 +202,14 @@ __global__ __launch_bounds__(256) void thin4_cout_kernel(const T4Args a) {
           for (int e = 0; e < KS; ++e)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-              acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[q * KS + e][c], v[(s + q) % RING][e][c], acc[s], 0, 0, 0);
+#pragma unroll
+              for (int g = 0; g < NG; ++g)
+                accg[g][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][q * KS + e][c], v[(s + q) % RING][e][c], accg[g][s], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+    f32x4* acc = accg[g];
     // fold the 16 K-blocks: lane bit 5 (b bit 3) halves the rows 8 -> 4, bit 4: 4 -> 2, bit 3: 2 -> 1,
     // bit 2 (b bit 0) halves the 4 channels -> 2.  Kept half is chosen by the lane's own bit.
     float h4[4][4];
@@ -242,15 +258,17 @@ __global__ __launch_bounds__(256) void thin4_cout_kernel(const T4Args a) {
     const int y = y0 + my_s;
     if (x < a.W && y < a.H) {
       const size_t pix = (size_t)(n * a.H + y) * a.W + x;
-      float t0 = o0 + bias0, t1 = o1 + bias1;
+      const int ch = 4 * g + my_c;
+      float t0 = o0 + bias0[g], t1 = o1 + bias1[g];
       if (a.res) {
-        if (my_c < a.Cout) t0 += a.res[pix * a.ldr + my_c];
-        if (my_c + 1 < a.Cout) t1 += a.res[pix * a.ldr + my_c + 1];
+        if (ch < a.Cout) t0 += a.res[pix * a.ldr + ch];
+        if (ch + 1 < a.Cout) t1 += a.res[pix * a.ldr + ch + 1];
       }
       float2 o;
-      o.x = my_c < a.Cout ? act_apply(t0, a.act, a.slope) : 0.f;
-      o.y = my_c + 1 < a.Cout ? act_apply(t1, a.act, a.slope) : 0.f;
-      if (my_c < ((a.Cout + 3) & ~3)) *(float2*)(a.out + pix * a.ldo + my_c) = o;
+      o.x = ch < a.Cout ? act_apply(t0, a.act, a.slope) : 0.f;
+      o.y = ch + 1 < a.Cout ? act_apply(t1, a.act, a.slope) : 0.f;
+      if (ch < ((a.Cout + 3) & ~3)) *(float2*)(a.out + pix * a.ldo + ch) = o;
+    }
     }
   }
 }
@@ -276,7 +294,7 @@ int thin4_on() {
 
 }  // namespace
 
-// 0 = no; 3 = thin-Cin (in has 4 channels); 4 = thin-Cout (Cout <= 4, Cin % 64 == 0).  SSG_THIN4 is a bit
+// 0 = no; 3 = thin-Cin (in has 4 channels); 4 = thin-Cout (Cout <= 8, Cin % 64 == 0).  SSG_THIN4 is a bit
 // mask (1 = thin-Cin, 2 = thin-Cout; default both).
 int ssg_thin4_conv_kind(const ssg_conv_desc* d) {
   if (d->C2 != 0 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox) return 0;
@@ -287,7 +305,7 @@ int ssg_thin4_conv_kind(const ssg_conv_desc* d) {
   if (!window_taps(d, tapidx)) return 0;
   if ((thin4_on() & 1) && d->C1 == 4 && d->kmode == 1 && d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) &&
       (!d->res || (d->ldr % 4 == 0 && !((uintptr_t)d->res & 15)))) return 3;
-  if ((thin4_on() & 2) && d->Cout <= 4 && d->C1 >= 64 && d->C1 % 64 == 0 && d->ldo % 2 == 0 && !((uintptr_t)d->out & 7)) return 4;
+  if ((thin4_on() & 2) && d->Cout <= 8 && d->C1 >= 64 && d->C1 % 64 == 0 && d->ldo % 2 == 0 && !((uintptr_t)d->out & 7)) return 4;
   return 0;
 }
 
@@ -313,8 +331,13 @@ int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
     if (ks1) hipLaunchKernelGGL(thin4_cin_kernel<1>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(thin4_cin_kernel<3>, grid, block, 0, st, a);
   } else {
-    if (ks1) hipLaunchKernelGGL(thin4_cout_kernel<1>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(thin4_cout_kernel<3>, grid, block, 0, st, a);
+    if (d->Cout <= 4) {
+      if (ks1) hipLaunchKernelGGL((thin4_cout_kernel<1, 1>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((thin4_cout_kernel<3, 1>), grid, block, 0, st, a);
+    } else {
+      if (ks1) hipLaunchKernelGGL((thin4_cout_kernel<1, 2>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((thin4_cout_kernel<3, 2>), grid, block, 0, st, a);
+    }
   }
   SSG_LAUNCH_CHECK();
   return SSG_OK;

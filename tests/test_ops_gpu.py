@@ -68,6 +68,7 @@ KERNEL_CASES = [
     (2, 3, 64, 37, 45, 3, 1, ('thin4_cin_kernel', 'thin4_cout_kernel', 'wgrad4_kernel<thin_cin>')),
     (1, 128, 4, 19, 23, 3, 1, ('thin4_cout_kernel', 'thin4_cin_kernel', 'wgrad4_kernel<thin_cout>')),
     (2, 64, 1, 16, 20, 1, 0, ('thin4_cout_kernel', 'thin4_cin_kernel', 'wgrad4_kernel<thin_cout>')),
+    (2, 128, 7, 21, 30, 3, 1, ('thin4_cout_kernel',)),                     # Cout 5..8: two output-channel groups
     (2, 64, 128, 37, 45, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<32,128>')),
     (4, 32, 128, 128, 192, 3, 1, ('conv_igemm_halo_kernel<128,128>', 'conv_igemm_kernel<256,32>', 'wgrad_halo_kernel<32,128>')),
     (1, 128, 64, 21, 70, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<64,64>')),
