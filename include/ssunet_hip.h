@@ -207,6 +207,10 @@ int ssg_adaptive_avgpool_flat_bwd_f32(const float* dy, int N, int H, int W, int 
 int ssg_spade_modulate_fwd_f32(const float* x, int ldx, const float* gb, int ldgb, int64_t P, int C, float* y, int ldy, void* stream);
 int ssg_spade_modulate_bwd_f32(const float* x, int ldx, const float* gb, int ldgb, const float* dy, int lddy, int64_t P, int C,
                                float* dx, int lddx, float* dgb, int lddgb, void* stream);
+/* the same pass that also returns the bias gradients of the gamma / beta convs (normalization.py:94-96):
+ * sums[0:C] = sum_p dy*x, sums[C:2C] = sum_p dy, fp64, deterministic; ws: ssg_bn_workspace_bytes(P, C) bytes */
+int ssg_spade_modulate_bwd_sums_f32(const float* x, int ldx, const float* gb, int ldgb, const float* dy, int lddy, int64_t P,
+                                    int C, float* dx, int lddx, float* dgb, int lddgb, double* sums, void* ws, void* stream);
 /* activation backward: dx = dy * (y > 0 ? 1 : slope) (+ add) */
 int ssg_act_bwd_f32(const float* y, int ldy, const float* dy, int lddy, int64_t P, int C, int act, float slope, float* dx, int lddx, void* stream);
 /* dst[p, 0:C] = src[p, 0:C]: channel-slice copy (materialised torch.cat of > 2 tensors, archs.py:910-925) */

@@ -85,6 +85,7 @@ SIGNATURES = {
     'ssg_adaptive_avgpool_flat_bwd_f32': [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     'ssg_spade_modulate_fwd_f32': [_P, _I, _P, _I, _L, _I, _P, _I, _P],
     'ssg_spade_modulate_bwd_f32': [_P, _I, _P, _I, _P, _I, _L, _I, _P, _I, _P, _I, _P],
+    'ssg_spade_modulate_bwd_sums_f32': [_P, _I, _P, _I, _P, _I, _L, _I, _P, _I, _P, _I, _P, _P, _P],
     'ssg_act_bwd_f32': [_P, _I, _P, _I, _L, _I, _I, _F, _P, _I, _P],
     'ssg_add_f32': [_P, _P, _L, _P, _P],
     'ssg_copy_channels_f32': [_P, _I, _L, _I, _P, _I, _P],

@@ -106,12 +106,15 @@ class _SpadeFn(torch.autograd.Function):
         n, c, h, w = x.shape
         dxm = new_nhwc(n, c, h, w, x.device)
         dgb = new_nhwc(n, 2 * c, h, w, x.device)
-        call('ssg_spade_modulate_bwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), ptr(dout), _ld(dout), n * h * w, c,
-             ptr(dxm), _ld(dxm), ptr(dgb), _ld(dgb), stream_ptr())
+        # modulate backward and the gamma / beta bias gradients (column sums of dgb) in one pass over the data
+        scratch = ops._ws(call('ssg_bn_workspace_bytes', n * h * w, c), x.device)
+        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        call('ssg_spade_modulate_bwd_sums_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), ptr(dout), _ld(dout), n * h * w, c,
+             ptr(dxm), _ld(dxm), ptr(dgb), _ld(dgb), ptr(sums), ptr(scratch), stream_ptr())
         dga, dbe = dgb[:, :c], dgb[:, c:]
         dwg = _conv_wgrad_impl(a, None, dga, wg.shape, 1, pad)
         dwb = _conv_wgrad_impl(a, None, dbe, wb.shape, 1, pad)
-        dbias_gb = _channel_sum(dgb, 2 * c)
+        dbias_gb = sums.float()
         nh = a.shape[1]
         da = _conv_dgrad_impl(dga, wg, 1, pad, h, w, 0, nh)
         da = _conv_dgrad_impl(dbe, wb, 1, pad, h, w, 0, nh, res=da)

@@ -98,6 +98,50 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
   }
 }
 
+// SPADE modulate backward fused with the bias gradients of the gamma / beta convs (normalization.py:116-121):
+//   dx = dy*(1+gamma), dgamma = dy*x, dbeta = dy, and per channel sum(dgamma) | sum(dbeta) -- the column sums
+// used to re-read the freshly written 2C-channel tensor; here they ride the producing pass (same block geometry and
+// fp64 partials as col_reduce_kernel, finished by col_reduce_final_kernel).
+__global__ __launch_bounds__(RED_BLOCK) void modulate_bwd_sums_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ gb, int ldgb, const float* __restrict__ dy, int lddy,
+    long long P, int C, float* __restrict__ dx, int lddx, float* __restrict__ dgb, int lddgb,
+    int TQ, int PR, long long rows_per_part, double* __restrict__ part /* [parts][2][C] */) {
+  __shared__ double red[2][RED_BLOCK][4];
+  const int tid = threadIdx.x;
+  const int tq = tid % TQ, pr = tid / TQ;
+  const int cq = blockIdx.y * TQ + tq;
+  const int CQ = C / 4;
+  const bool cok = cq < CQ;
+  const long long p0 = (long long)blockIdx.x * rows_per_part;
+  long long p1 = p0 + rows_per_part; if (p1 > P) p1 = P;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (cok) {
+    for (long long p = p0 + pr; p < p1; p += PR) {
+      const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
+      const f32x4 g = *(const f32x4*)(gb + p * ldgb + 4 * cq);
+      const f32x4 d = *(const f32x4*)(dy + p * lddy + 4 * cq);
+      const f32x4 dg = d * xv;
+      *(f32x4*)(dx + p * lddx + 4 * cq) = d * (1.f + g);
+      *(f32x4*)(dgb + p * lddgb + 4 * cq) = dg;
+      *(f32x4*)(dgb + p * lddgb + C + 4 * cq) = d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += (double)dg[e]; s2[e] += (double)d[e]; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+  __syncthreads();
+  if (pr == 0 && cok) {
+    double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    for (int r = 0; r < PR; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a1[e] += red[0][r * TQ + tq][e]; a2[e] += red[1][r * TQ + tq][e]; }
+    double* dst = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[4 * cq + e] = a1[e]; dst[C + 4 * cq + e] = a2[e]; }
+  }
+}
+
 // Second stage: 32 channels x 32 part-lanes per block; each lane adds every 32nd partial row in
 // row order, then the 32 lane sums are added in lane order -> fixed summation order (bitwise
 // reproducible), 1/32 of the serial chain of a one-thread-per-channel loop.
@@ -303,6 +347,22 @@ extern "C" int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float*
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), (size_t)5 * C * sizeof(double), (hipStream_t)stream, x, y, dy,
                      P, C, ldx, ldy, lddy, mean, invstd, weight, scale, shift, sums, count, act, slope, dx, lddx, dres, lddres,
                      dweight, dbias);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+extern "C" int ssg_spade_modulate_bwd_sums_f32(const float* x, int ldx, const float* gb, int ldgb, const float* dy, int lddy, int64_t P,
+                                               int C, float* dx, int lddx, float* dgb, int lddgb, double* sums, void* ws, void* stream) {
+  SSG_REQUIRE(x && gb && dy && dx && dgb && sums && ws && P > 0 && C > 0 && C % 4 == 0 && ldgb >= 2 * C && lddgb >= 2 * C, SSG_EINVAL,
+              "modulate_bwd_sums: bad args");
+  const RedGeom g = red_geom(P, C);
+  double* part = (double*)ws;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(modulate_bwd_sums_kernel, dim3((unsigned)g.parts, (unsigned)g.groups), dim3(RED_BLOCK), 0, st, x, ldx, gb, ldgb, dy, lddy,
+                     (long long)P, C, dx, lddx, dgb, lddgb, g.TQ, g.PR, g.rows_per_part, part);
+  SSG_LAUNCH_CHECK();
+  // sums[0:C] = sum dgamma, sums[C:2C] = sum dbeta (ssg_bn_workspace_bytes(P, C) bytes of workspace)
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C, sums, nullptr);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
