@@ -86,24 +86,36 @@ __global__ __launch_bounds__(LOSS_BLOCK) void seg_loss_partial_kernel(const floa
   }
 }
 
-__global__ void seg_loss_final_kernel(const double* __restrict__ part, int N, int bps, long long S, int C, int mc0,
-                                      float* __restrict__ res, double* __restrict__ stats) {
-  // single block; thread k < NQ*? -- do it serially per sample on a few threads: N is small (<= 1024)
+// Single block: thread (n, k) adds the per-block partials of quantity k of sample n in block order (samples in
+// chunks of 64), then one thread combines the samples in sample order -- the summation order of a serial loop.
+constexpr int FINAL_CHUNK = 64;
+__global__ __launch_bounds__(1024) void seg_loss_final_kernel(const double* __restrict__ part, int N, int bps, long long S, int C, int mc0,
+                                                            float* __restrict__ res, double* __restrict__ stats) {
+  __shared__ double q[FINAL_CHUNK][NQ];
   __shared__ double tot[NQ];
   __shared__ double dice_sum;
   if (threadIdx.x < NQ) tot[threadIdx.x] = 0;
   if (threadIdx.x == 0) dice_sum = 0;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int n = 0; n < N; ++n) {
-      double q[NQ];
-      for (int k = 0; k < NQ; ++k) q[k] = 0;
-      for (int b = 0; b < bps; ++b)
-        for (int k = 0; k < NQ; ++k) q[k] += part[((size_t)n * bps + b) * NQ + k];
-      stats[n * 3 + 0] = q[0]; stats[n * 3 + 1] = q[1]; stats[n * 3 + 2] = q[2];
-      dice_sum += (2.0 * q[0] + 1e-5) / (q[1] + q[2] + 1e-5);
-      for (int k = 3; k < NQ; ++k) tot[k] += q[k];
+  for (int n0 = 0; n0 < N; n0 += FINAL_CHUNK) {
+    const int nn = N - n0 < FINAL_CHUNK ? N - n0 : FINAL_CHUNK;
+    for (int t = threadIdx.x; t < nn * NQ; t += blockDim.x) {
+      const int n = t / NQ, k = t - n * NQ;
+      double a = 0;
+      for (int b = 0; b < bps; ++b) a += part[((size_t)(n0 + n) * bps + b) * NQ + k];
+      q[n][k] = a;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int n = 0; n < nn; ++n) {
+        stats[(n0 + n) * 3 + 0] = q[n][0]; stats[(n0 + n) * 3 + 1] = q[n][1]; stats[(n0 + n) * 3 + 2] = q[n][2];
+        dice_sum += (2.0 * q[n][0] + 1e-5) / (q[n][1] + q[n][2] + 1e-5);
+        for (int k = 3; k < NQ; ++k) tot[k] += q[n][k];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
     const double numel = (double)N * (double)S * (double)C;
     const double bce = tot[3] / numel;
     const double mse = tot[4] / numel;
@@ -191,7 +203,7 @@ extern "C" int ssg_seg_loss_fwd_f32(const float* x, int ldx, const float* t, int
   hipLaunchKernelGGL(seg_loss_partial_kernel, dim3((unsigned)g.bps, (unsigned)N), dim3(LOSS_BLOCK), 0, st, x, ldx, t, ldt, (long long)S, C, mc0,
                      g.pix_per_block, (double*)ws);
   SSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(seg_loss_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, N, g.bps, (long long)S, C, mc0, res, stats);
+  hipLaunchKernelGGL(seg_loss_final_kernel, dim3(1), dim3(1024), 0, st, (const double*)ws, N, g.bps, (long long)S, C, mc0, res, stats);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
