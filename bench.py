@@ -33,7 +33,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 # HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
 # separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950):
 # profiles/r01_e_pmc_hbm_traffic_per_kernel.csv (algorithmic bytes of the same launches: tools/shapes.py).  Static: bench.py cannot run the profiler on itself.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {'conv_igemm_halo_kernel<128,128>': 763470717, 'conv_igemm_halo_kernel<128,64>': 863891610,
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {'conv_igemm_halo_kernel<128,128>': 764166084, 'conv_igemm_halo_kernel<128,64>': 864554588,
                                 'conv_igemm_halo_kernel<256,64>': 1648735232,
                                 'wgrad_halo_kernel<32,128>': 1406952340, 'wgrad_halo_kernel<64,64>': 3899951360,
                                 'conv_igemm_dma_kernel<128,128>': 346560165, 'conv_igemm_dma_kernel<256,64>': 1234910627,
