@@ -83,7 +83,7 @@ int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream);
  * else goes to the MFMA implicit GEMM above.  Same descriptor, same semantics.
  * ssg_conv2d_kernel_id: 0..2 = conv_igemm_kernel<128,128>/<256,64>/<256,32> (register-staged),
  * 30/31/32 = conv_igemm_halo_kernel<128,128>/<256,64>/<128,64> (LDS-resident halo tile: the default for the 9 taps of
- * a 3x3 window at unit stride), 20/21 = conv_igemm_dma_kernel<128,128>/<256,64> (LDS-DMA pipeline, the default for Cin % 16 == 0
+ * a 3x3 window at unit stride), 20/21/22 = conv_igemm_dma_kernel<128,128>/<256,64>/<128,64> (LDS-DMA pipeline, the default for Cin % 16 == 0
  * and Cout > 32), 12/13 = thin4 kernels on the 4x4x1 MFMA (4-channel input / Cout <= 4 with Cin % 64 == 0),
  * 10 = thin small-Cout, 11 = thin small-Cin (VALU; profiling labels). */
 int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream);

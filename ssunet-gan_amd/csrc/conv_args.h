@@ -21,6 +21,7 @@ struct ConvArgs {
 
 // conv_igemm_dma.hip: LDS-DMA pipeline for kmode 0, Cout > 32 (variant 0 = <128,128>, 1 = <256,64>)
 int ssg_conv_igemm_dma_launch(const ConvArgs& a, int variant, hipStream_t st);
+int ssg_conv_dma_variant(const ConvArgs& a, int variant);    // 0 = <128,128>, 1 = <256,64>, 2 = <128,64> (short K)
 
 // conv_igemm_halo.hip: LDS-resident halo tile for the 9 taps of a 3x3 window (variant 0 = <128,128>, 1 = <256,64>)
 bool ssg_conv_halo_ok(const ConvArgs& a);

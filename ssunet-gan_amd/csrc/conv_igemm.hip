@@ -333,7 +333,7 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
 
 // Dispatcher: thin VALU kernels for the <= 8-channel cases, MFMA implicit GEMM otherwise.
 // ssg_conv2d_kernel_id reports which kernel a descriptor maps to (for profiling labels):
-//   0..2 = conv_igemm<128,128> / <256,64> / <256,32>, 20/21 = conv_igemm_dma<128,128> / <256,64>,
+//   0..2 = conv_igemm<128,128> / <256,64> / <256,32>, 20/21/22 = conv_igemm_dma<128,128> / <256,64> / <128,64>,
 //   30/31/32 = conv_igemm_halo<128,128> / <256,64> / <128,64>,
 //   12 = thin4 (4x4x1 MFMA) 4-channel input, 13 = thin4 Cout <= 4, 10 = thin small-Cout (VALU), 11 = thin small-Cin (VALU).
 extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
@@ -342,7 +342,7 @@ extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
   if (k4) return 9 + k4;
   const int k = ssg_thin_conv_kind(d);
   if (k) return 9 + k;
-  if (uses_dma(d)) return uses_halo(to_args(d)) ? 30 + ssg_conv_halo_variant(to_args(d), pick_variant(d)) : 20 + pick_variant(d);
+  if (uses_dma(d)) return uses_halo(to_args(d)) ? 30 + ssg_conv_halo_variant(to_args(d), pick_variant(d)) : 20 + ssg_conv_dma_variant(to_args(d), pick_variant(d));
   return pick_variant(d);
 }
 

@@ -226,7 +226,19 @@ int launch(const ConvArgs& a0, hipStream_t st) {
 
 // Called by ssg_conv2d_igemm_f32 (conv_igemm.hip) for kmode 0, Cout > 32, no bnpart.
 // (A <256,128> tile with 128 x 64 per wave was measured: 284 VGPRs -> one wave per SIMD, 10-50% slower.)
+// 0 = <128,128>, 1 = <256,64>, 2 = <128,64>.  Short K loops (1x1 convs, the 1/2/2/4-tap parity launches of a
+// stride-2 input gradient): a tile is mostly prologue and epilogue, and four small workgroups per CU overlap those
+// better than two or three large ones (measured: <= 16 steps -1.4 ms/step, 36 or 72 no better).
+int ssg_conv_dma_variant(const ConvArgs& a, int variant) {
+  static const int small_k = [] { const char* e = getenv("SSG_DMA_SMALLK"); return e ? atoi(e) : 16; }();
+  if (small_k && a.nsteps <= small_k) return 2;
+  return variant == 0 ? 0 : 1;
+}
+
 int ssg_conv_igemm_dma_launch(const ConvArgs& a, int variant, hipStream_t st) {
-  if (variant == 0) return launch<128, 128, 2, 2>(a, st);
-  return launch<256, 64, 4, 1>(a, st);
+  switch (ssg_conv_dma_variant(a, variant)) {
+    case 0: return launch<128, 128, 2, 2>(a, st);
+    case 2: return launch<128, 64, 2, 2>(a, st);
+    default: return launch<256, 64, 4, 1>(a, st);
+  }
 }

@@ -173,7 +173,7 @@ PROFILE_SHAPES = False      # debug: append the launch geometry to the label
 
 
 _CONV_LABELS = {0: 'conv_igemm_kernel<128,128>', 1: 'conv_igemm_kernel<256,64>', 2: 'conv_igemm_kernel<256,32>',
-                20: 'conv_igemm_dma_kernel<128,128>', 21: 'conv_igemm_dma_kernel<256,64>',
+                20: 'conv_igemm_dma_kernel<128,128>', 21: 'conv_igemm_dma_kernel<256,64>', 22: 'conv_igemm_dma_kernel<128,64>',
                 30: 'conv_igemm_halo_kernel<128,128>', 31: 'conv_igemm_halo_kernel<256,64>', 32: 'conv_igemm_halo_kernel<128,64>',
                 10: 'thin_small_cout_kernel', 11: 'thin_small_cin_kernel',
                 12: 'thin4_cin_kernel', 13: 'thin4_cout_kernel'}

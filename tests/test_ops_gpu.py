@@ -74,7 +74,9 @@ KERNEL_CASES = [
     (1, 128, 64, 21, 70, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<64,64>')),
     (1, 192, 64, 17, 40, 3, 1, ('conv_igemm_halo_kernel<256,64>', 'conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<64,64>')),
     (1, 96, 64, 9, 33, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_dma_kernel<128,64>')),
-    (2, 48, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,128>', 'conv_igemm_dma_kernel<256,64>', 'wgrad_dma_kernel<128,128>')),
+    (2, 48, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,128>')),            # short K: the small DMA tile
+    (1, 320, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,128>', 'conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,128>')),
+    (1, 320, 48, 14, 14, 1, 0, ('conv_igemm_dma_kernel<256,64>', 'conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,64>')),
 ]
 
 
