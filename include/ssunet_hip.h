@@ -289,7 +289,9 @@ int ssg_mul_bwd_f32(const float* a, int lda, const float* b, int ldb, const floa
 /* squeeze-excite plumbing (model.py:76-80): y[n,p,c] = x[n,p,c]*s[n,c]; out[n,c] = scale*sum_p a[n,p,c]*(b?b[n,p,c]:1)
  * (global average pool and the gate's gradient); y[n,p,c] = scale*s[n,c] (average-pool backward) */
 int ssg_channel_scale_fwd_f32(const float* x, int ldx, const float* s, int N, int64_t S, int C, float* y, int ldy, void* stream);
-int ssg_sample_channel_sum_f32(const float* a, int lda, const float* b, int ldb, int N, int64_t S, int C, float scale, float* out, void* stream);
+int64_t ssg_sample_channel_sum_workspace_bytes(int N, int64_t S, int C);
+int ssg_sample_channel_sum_f32(const float* a, int lda, const float* b, int ldb, int N, int64_t S, int C, float scale, float* out,
+                               void* ws, void* stream);
 int ssg_broadcast_rows_f32(const float* s, int N, int64_t S, int C, float scale, float* y, int ldy, void* stream);
 /* Spectral norm (spectral_norm.py:38-88): power iteration on W [rows][cols] with in-place u [rows],
  * v [cols]; W_out = W / sigma, sigma = u.(W v).  Backward treats u, v as constants:

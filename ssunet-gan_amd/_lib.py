@@ -109,7 +109,8 @@ SIGNATURES = {
     'ssg_mul_fwd_f32': [_P, _I, _P, _I, _L, _I, _P, _I, _P],
     'ssg_mul_bwd_f32': [_P, _I, _P, _I, _P, _I, _L, _I, _P, _I, _P, _I, _P],
     'ssg_channel_scale_fwd_f32': [_P, _I, _P, _I, _L, _I, _P, _I, _P],
-    'ssg_sample_channel_sum_f32': [_P, _I, _P, _I, _I, _L, _I, _F, _P, _P],
+    'ssg_sample_channel_sum_workspace_bytes': [_I, _L, _I],
+    'ssg_sample_channel_sum_f32': [_P, _I, _P, _I, _I, _L, _I, _F, _P, _P, _P],
     'ssg_broadcast_rows_f32': [_P, _I, _L, _I, _F, _P, _I, _P],
     'ssg_spectral_norm_workspace_bytes': [_I, _I],
     'ssg_spectral_norm_fwd_f32': [_P, _I, _I, _P, _P, _I, _D, _P, _P, _P, _P],
@@ -128,6 +129,7 @@ _RESTYPES = {
     'ssg_dwconv2d_wgrad_workspace_bytes': C.c_int64,
     'ssg_spectral_norm_workspace_bytes': C.c_int64,
     'ssg_linear_fwd_workspace_bytes': C.c_int64,
+    'ssg_sample_channel_sum_workspace_bytes': C.c_int64,
 }
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_igemm_mtiles', 'ssg_conv2d_kernel_id', 'ssg_conv2d_wgrad_kernel_id'}
 

@@ -1031,7 +1031,8 @@ class _GlobalAvgPool(torch.autograd.Function):
         if c % 4:
             raise ValueError('global_avgpool: C %% 4 != 0')
         y = new_nhwc(n, c, 1, 1, x.device)
-        call('ssg_sample_channel_sum_f32', ptr(x), _ld(x), None, 0, n, h * w, c, 1.0 / (h * w), ptr(y), stream_ptr())
+        ws = _ws(call('ssg_sample_channel_sum_workspace_bytes', n, h * w, c), x.device)
+        call('ssg_sample_channel_sum_f32', ptr(x), _ld(x), None, 0, n, h * w, c, 1.0 / (h * w), ptr(y), ptr(ws), stream_ptr())
         ctx.cfg = (n, c, h, w)
         return y
 
@@ -1072,7 +1073,8 @@ class _ChannelScale(torch.autograd.Function):
         dx = new_nhwc(n, c, h, w, x.device)
         call('ssg_channel_scale_fwd_f32', ptr(dy), _ld(dy), ptr(s), n, h * w, c, ptr(dx), _ld(dx), stream_ptr())
         ds = new_nhwc(n, c, 1, 1, x.device)
-        call('ssg_sample_channel_sum_f32', ptr(dy), _ld(dy), ptr(x), _ld(x), n, h * w, c, 1.0, ptr(ds), stream_ptr())
+        ws = _ws(call('ssg_sample_channel_sum_workspace_bytes', n, h * w, c), x.device)
+        call('ssg_sample_channel_sum_f32', ptr(dy), _ld(dy), ptr(x), _ld(x), n, h * w, c, 1.0, ptr(ds), ptr(ws), stream_ptr())
         return dx, ds
 
 
