@@ -122,6 +122,140 @@ __global__ void dw_wgrad_final_kernel(const double* __restrict__ part, int parts
   dw[(size_t)c * KK + t] = (float)s;
 }
 
+// ---------------------------------------------------------------- stride-1 depthwise, register tiled
+// The one-thread-per-output kernels above issue KH*KW 16-B loads (+ 4 weight dwords) per output quad: at 9x9
+// (xResidualBlock) they are L1-issue bound at ~1.5 TFLOP/s.  For unit stride:
+//   * forward and input gradient are the same kernel (the gradient is the correlation with the flipped kernel and
+//     pad' = K-1-pad): a thread owns XT = 4 consecutive outputs of one channel quad, loads each input row segment
+//     (XT+KW-1 quads) once per kernel row and reuses it for all KW taps; the block's weights sit in LDS as
+//     [tap][16 quads][4] so one ds_read_b128 serves 4 channels x XT outputs;
+//   * the weight gradient runs one kernel ROW of taps per workgroup (grid.z = KH, not KH*KW): dout is re-read KH
+//     times instead of KH*KW, KW x 4 fp64 accumulators per thread, ordered two-stage reduction as before.
+struct DwS1Args {
+  const float* src; const float* w; const float* bias; float* dst;
+  int N, SH, SW, DH, DW_, C, lds_, ldd, KH, pt, pl, flip;      // source image SH x SW, destination DH x DW_
+};
+constexpr int DW_XT = 4;
+
+template <int KW>
+__global__ __launch_bounds__(256) void dw_s1_kernel(const DwS1Args a) {
+  extern __shared__ float w_s[];                         // [KH*KW][16][4]
+  const int KK = a.KH * KW;
+  const int tid = threadIdx.x, tq = tid & 15, xg = tid >> 4;
+  const int cq0 = blockIdx.z * 16;
+  for (int idx = tid; idx < KK * 64; idx += 256) {
+    const int t = idx >> 6, c = idx & 63;
+    const int ch = cq0 * 4 + c;
+    w_s[idx] = ch < a.C ? a.w[(size_t)ch * KK + (a.flip ? KK - 1 - t : t)] : 0.f;
+  }
+  __syncthreads();
+  const int cq = cq0 + tq;
+  if (cq * 4 >= a.C) return;
+  const int oy = blockIdx.y % a.DH, n = blockIdx.y / a.DH;
+  const int x0 = blockIdx.x * (16 * DW_XT) + xg * DW_XT;
+  if (x0 >= a.DW_) return;
+  f32x4 acc[DW_XT];
+  const f32x4 b0 = a.bias ? *(const f32x4*)(a.bias + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < DW_XT; ++j) acc[j] = b0;
+  for (int ky = 0; ky < a.KH; ++ky) {
+    const int iy = oy + ky - a.pt;
+    if ((unsigned)iy >= (unsigned)a.SH) continue;
+    const float* row = a.src + ((size_t)(n * a.SH + iy) * a.SW) * a.lds_ + 4 * cq;
+    f32x4 v[DW_XT + KW - 1];
+#pragma unroll
+    for (int j = 0; j < DW_XT + KW - 1; ++j) {
+      const int ix = x0 + j - a.pl;
+      v[j] = (unsigned)ix < (unsigned)a.SW ? *(const f32x4*)(row + (size_t)ix * a.lds_) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* wrow = w_s + (ky * KW) * 64 + tq * 4;
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {
+      const f32x4 wv = *(const f32x4*)(wrow + kx * 64);
+#pragma unroll
+      for (int j = 0; j < DW_XT; ++j) acc[j] += v[j + kx] * wv;
+    }
+  }
+  float* orow = a.dst + ((size_t)(n * a.DH + oy) * a.DW_) * a.ldd + 4 * cq;
+#pragma unroll
+  for (int j = 0; j < DW_XT; ++j)
+    if (x0 + j < a.DW_) *(f32x4*)(orow + (size_t)(x0 + j) * a.ldd) = acc[j];
+}
+
+template <int KW>
+int launch_dw_s1(const DwS1Args& a, hipStream_t st) {
+  const dim3 grid((unsigned)((a.DW_ + 16 * DW_XT - 1) / (16 * DW_XT)), (unsigned)(a.N * a.DH), (unsigned)((a.C / 4 + 15) / 16));
+  hipLaunchKernelGGL(dw_s1_kernel<KW>, grid, dim3(256), (size_t)a.KH * KW * 64 * sizeof(float), st, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+// returns -1 if the shape is not covered (caller falls back to the generic kernel)
+int dw_s1_dispatch(const DwS1Args& a, int KW, hipStream_t st) {
+  if ((long long)a.N * a.DH > 65535 || (a.C / 4 + 15) / 16 > 65535) return -1;     // grid.y / grid.z limits
+  switch (KW) {
+    case 3: return launch_dw_s1<3>(a, st);
+    case 5: return launch_dw_s1<5>(a, st);
+    case 7: return launch_dw_s1<7>(a, st);
+    case 9: return launch_dw_s1<9>(a, st);
+    default: return -1;
+  }
+}
+
+// weight gradient, one kernel row ky per blockIdx.z: s[kx][e] += dout[p][c] * in[p + (ky, kx)][c]
+template <int KW>
+__global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs a, long long rows_per_part, double* __restrict__ part) {
+  __shared__ double red[256][4];
+  const int tid = threadIdx.x, tq = tid % DW_TQ, pr = tid / DW_TQ, PR = 256 / DW_TQ;
+  const int CQ = a.C / 4, cq = blockIdx.y * DW_TQ + tq;
+  const int ky = blockIdx.z;
+  const long long P = (long long)a.N * a.OH * a.OW;
+  const long long p0 = (long long)blockIdx.x * rows_per_part;
+  long long p1 = p0 + rows_per_part; if (p1 > P) p1 = P;
+  double s[KW][4];
+#pragma unroll
+  for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[kx][e] = 0;
+  if (cq < CQ) {
+    for (long long p = p0 + pr; p < p1; p += PR) {
+      const int ox = (int)(p % a.OW); const long long r = p / a.OW;
+      const int oy = (int)(r % a.OH); const int n = (int)(r / a.OH);
+      const int iy = oy + ky - a.pt;
+      if ((unsigned)iy >= (unsigned)a.H) continue;
+      const f32x4 g = *(const f32x4*)(a.dout + (size_t)p * a.ldo + 4 * cq);
+      const float* row = a.in + ((size_t)(n * a.H + iy) * a.W) * a.ld + 4 * cq;
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+        const int ix = ox + kx - a.pl;
+        if ((unsigned)ix < (unsigned)a.W) {
+          const f32x4 v = *(const f32x4*)(row + (size_t)ix * a.ld);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[kx][e] += (double)g[e] * (double)v[e];
+        }
+      }
+    }
+  }
+  for (int kx = 0; kx < KW; ++kx) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[tid][e] = s[kx][e];
+    __syncthreads();
+    if (pr == 0 && cq < CQ) {
+      double tot[4] = {0, 0, 0, 0};
+      for (int r = 0; r < PR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tot[e] += red[r * DW_TQ + tq][e];
+      double* dst = part + ((size_t)blockIdx.x * (a.KH * KW) + ky * KW + kx) * a.C + 4 * cq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[e] = tot[e];
+    }
+  }
+}
+template <int KW>
+void launch_dw_wgrad_s1(const DwArgs& a, long long parts, long long rpp, double* ws, hipStream_t st) {
+  hipLaunchKernelGGL(dw_wgrad_s1_kernel<KW>, dim3((unsigned)parts, (unsigned)((a.C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)a.KH), dim3(256), 0, st, a, rpp, ws);
+}
+
 // ---------------------------------------------------------------- unary ops (fwd / bwd)
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -261,6 +395,11 @@ extern "C" int ssg_dwconv2d_fwd_f32(const float* in, int N, int H, int W, int C,
   int rc = dw_check("dwconv_fwd", in, N, H, W, C, ld, KH, KW, stride);
   if (rc) return rc;
   SSG_REQUIRE(w && out && OH > 0 && OW > 0 && ldo % 4 == 0, SSG_EINVAL, "dwconv_fwd: bad output");
+  if (stride == 1 && ssg_aligned16(in) && ssg_aligned16(out)) {
+    const DwS1Args s1{in, w, bias, out, N, H, W, OH, OW, C, ld, ldo, KH, pad_top, pad_left, 0};
+    rc = dw_s1_dispatch(s1, KW, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   DwArgs a{in, w, bias, nullptr, out, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, ldo};
   hipLaunchKernelGGL(dw_fwd_kernel, dim3(elem_grid((long long)N * OH * OW * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
   SSG_LAUNCH_CHECK();
@@ -272,6 +411,12 @@ extern "C" int ssg_dwconv2d_dgrad_f32(const float* dout, int lddo, int N, int H,
   int rc = dw_check("dwconv_dgrad", dout, N, OH, OW, C, lddo, KH, KW, stride);
   if (rc) return rc;
   SSG_REQUIRE(w && dx && H > 0 && W > 0 && lddx % 4 == 0, SSG_EINVAL, "dwconv_dgrad: bad output");
+  if (stride == 1 && ssg_aligned16(dout) && ssg_aligned16(dx)) {
+    // dx = correlation of dout with the flipped kernel, pads K-1-pad
+    const DwS1Args s1{dout, w, nullptr, dx, N, OH, OW, H, W, C, lddo, lddx, KH, KH - 1 - pad_top, KW - 1 - pad_left, 1};
+    rc = dw_s1_dispatch(s1, KW, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   DwArgs a{nullptr, w, nullptr, dout, dx, N, H, W, C, lddx, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
   hipLaunchKernelGGL(dw_dgrad_kernel, dim3(elem_grid((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
   SSG_LAUNCH_CHECK();
@@ -295,6 +440,12 @@ extern "C" int ssg_dwconv2d_wgrad_f32(const float* in, int N, int H, int W, int 
   parts = (P + rpp - 1) / rpp;
   DwArgs a{in, nullptr, nullptr, dout, nullptr, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
   hipStream_t st = (hipStream_t)stream;
+  if (stride == 1 && (KW == 3 || KW == 5 || KW == 7 || KW == 9)) {
+    if (KW == 3) launch_dw_wgrad_s1<3>(a, parts, rpp, (double*)ws, st);
+    else if (KW == 5) launch_dw_wgrad_s1<5>(a, parts, rpp, (double*)ws, st);
+    else if (KW == 7) launch_dw_wgrad_s1<7>(a, parts, rpp, (double*)ws, st);
+    else launch_dw_wgrad_s1<9>(a, parts, rpp, (double*)ws, st);
+  } else
   hipLaunchKernelGGL(dw_wgrad_partial_kernel, dim3((unsigned)parts, (unsigned)((C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)(KH * KW)), dim3(256), 0, st,
                      a, rpp, (double*)ws);
   SSG_LAUNCH_CHECK();

@@ -223,6 +223,36 @@ def test_batch_norm_act(pkg, dev, shape, act, res):
         _close(rd.grad, rref.grad, 1e-6, 1e-6, 'bn dres')
 
 
+@pytest.mark.parametrize('case', [
+    # n, c, h, w, k, stride, padding (int or (top, bottom, left, right))
+    (2, 36, 19, 23, 3, 1, 1), (1, 64, 17, 70, 5, 1, 2), (2, 8, 21, 33, 7, 1, 3), (1, 72, 30, 45, 9, 1, 4),
+    (2, 24, 16, 18, 3, 1, (0, 2, 0, 2)),            # asymmetric "static same" padding, stride 1
+    (2, 40, 17, 19, 5, 2, (1, 2, 1, 2)), (1, 16, 12, 14, 3, 2, 1),       # stride 2: the generic kernels
+])
+def test_dwconv2d(pkg, dev, case):
+    """Depthwise conv forward / input gradient / weight gradient (register-tiled stride-1 kernels and the generic ones)."""
+    n, c, h, w, k, stride, pad = case
+    g = torch.Generator().manual_seed(c * 100 + k)
+    x = torch.randn(n, c, h, w, generator=g); wt = torch.randn(c, 1, k, k, generator=g) / k; b = torch.randn(c, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, wt, b)]
+    xin = ref[0]
+    if isinstance(pad, tuple):
+        xin = F.pad(ref[0], (pad[2], pad[3], pad[0], pad[1]))
+        yr = F.conv2d(xin, ref[1], ref[2], stride, 0, groups=c)
+    else:
+        yr = F.conv2d(xin, ref[1], ref[2], stride, pad, groups=c)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    d = [t.to(dev).requires_grad_(True) for t in (x, wt, b)]
+    yd = pkg.ops.dwconv2d(d[0], d[1], d[2], stride, pad)
+    assert tuple(yd.shape) == tuple(yr.shape)
+    yd.backward(dy.to(dev))
+    _close(yd, yr, 1e-5, 1e-5, 'dw fwd')
+    _close(d[0].grad, ref[0].grad, 1e-5, 1e-5, 'dw dgrad')
+    _close(d[1].grad, ref[1].grad, 2e-5, 2e-5 * math.sqrt(n * h * w), 'dw wgrad')
+    _close(d[2].grad, ref[2].grad, 2e-5, 1e-5 * math.sqrt(n * h * w), 'dw bias grad')
+
+
 def test_pixel_gate(pkg, dev):
     """Attention gate x * sigmoid(psi) with a one-channel psi (Attention_block, archs.py:138-144)."""
     g = torch.Generator().manual_seed(77)
