@@ -16,6 +16,7 @@
 //     The barrier both publishes step s (every wave has waited for its own pieces) and proves
 //     stage (s+2)%3 == (s-1)%3 is no longer read.
 #include "common.h"
+#include "lds_dma.h"
 #include "conv_args.h"
 
 #ifndef SSG_EXPERIMENT
@@ -26,12 +27,6 @@ namespace {
 
 __device__ __attribute__((aligned(64))) float ssg_zero_page[64];
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-__device__ __forceinline__ void dma16(const float* src, float* lds_dst) {
-  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
-}
 
 #ifndef SSG_DMA_STAGES
 #define SSG_DMA_STAGES 3

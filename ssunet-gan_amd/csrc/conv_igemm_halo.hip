@@ -19,23 +19,14 @@
 //   * LDS image, XOR swizzle (16-B position p of row r holds channel quad p ^ ((r>>2)&3)), zero page
 //     for out-of-image pixels and the epilogue are those of conv_igemm_dma.hip.
 #include "common.h"
+#include "lds_dma.h"
 #include "conv_args.h"
 
 namespace {
 
 __device__ __attribute__((aligned(64))) float ssg_zero_page_h[64];
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
 
-__device__ __forceinline__ void dma16(const float* src, float* lds_dst) {
-  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) {

@@ -7,17 +7,13 @@
 //   * shifted/out-of-image taps and the pixel tail read a zero page instead of being predicated;
 //   * the per-lane pixel coordinate advances incrementally (no divisions in the loop).
 #include "common.h"
+#include "lds_dma.h"
 #include "conv_wgrad_args.h"
 
 namespace {
 
 __device__ __attribute__((aligned(64))) float ssg_zero_page_w[64];
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-__device__ __forceinline__ void dma16(const float* src, float* lds_dst) {
-  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
-}
 
 constexpr int BKP = 16;
 constexpr int NSTAGE = 3;

@@ -13,17 +13,13 @@
 //     3 stages, two K-steps in flight across the one barrier per step; out-of-image window pixels and
 //     the ragged end of an image row read a zero page.
 #include "common.h"
+#include "lds_dma.h"
 #include "conv_wgrad_args.h"
 
 namespace {
 
 __device__ __attribute__((aligned(64))) float ssg_zero_page_wh[64];
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-__device__ __forceinline__ void dma16(const float* src, float* lds_dst) {
-  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
-}
 
 constexpr int BKP = 16;          // pixels per K-step (one run inside an image row)
 constexpr int WW = BKP + 2;      // window width
