@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libssunet_hip.so')
+# SSG_LIB_PATH: load another build of the library (diagnostic builds of tools/clock_probe.py); default: the in-tree .so
+LIB_PATH = os.environ.get('SSG_LIB_PATH') or os.path.join(_HERE, 'libssunet_hip.so')
 MAX_TAPS = 9
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 

@@ -28,6 +28,11 @@ __device__ __attribute__((aligned(64))) float ssg_zero_page_h[64];
 
 
 
+#ifdef SSG_CLOCK_PROBE
+// diagnostic build only (tools/clock_probe.py): per workgroup (shader cycles, 100-MHz ticks) spent in the main loop
+__device__ unsigned long long* ssg_probe_buf = nullptr;
+#endif
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) {
   constexpr int TH = BM / 32, TW = 32;
@@ -134,6 +139,9 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
   // class below (has_last = the wave owns a piece with index k = APW-1).
   const bool has_last = wave + 4 * (APW - 1) < AP;
 
+#ifdef SSG_CLOCK_PROBE
+  const unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const float* Abuf = lds + (chunk & 1) * ABUF;
 #pragma unroll
@@ -177,6 +185,12 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
   }
   // drain the dummy pieces before the workgroup's LDS can be handed to another workgroup
   wait_vmcnt<0>();
+#ifdef SSG_CLOCK_PROBE
+  if (ssg_probe_buf && tid == 0) {
+    ssg_probe_buf[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - pt0;
+    ssg_probe_buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - pr0;
+  }
+#endif
 
   // ---- epilogue (identical to conv_igemm.hip): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -226,6 +240,13 @@ int launch(const ConvArgs& a0, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef SSG_CLOCK_PROBE
+extern "C" int ssg_debug_set_probe_buffer(void* p) {
+  unsigned long long* v = (unsigned long long*)p;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(ssg_probe_buf), &v, sizeof(v));
+}
+#endif
 
 // the 9 taps must be the 9 positions of the 3x3 window (any order), unit input stride
 bool ssg_conv_halo_ok(const ConvArgs& a) {
