@@ -2,7 +2,12 @@
 """Headline benchmark: train images/sec of the ssUnet-GAN G+D step on synthetic 3x512x512 tiles.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+N > 1 runs one rank per GPU over RCCL.  Either the caller starts the ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: RANK/WORLD_SIZE are in the
+environment) or, when they are not there, this process starts them itself: the parent never touches HIP, runs
+torch.distributed.run as a CHILD process, relays rank 0's JSON line and exits with the child's status.  A rank whose
+WORLD_SIZE differs from --gpus, or whose backend is not RCCL ("nccl") without SSG_DIST_BACKEND saying so, exits non-zero.
 
 One "step" = one pass of the hot path (train_seg_gan.py:182-233: G fwd+bwd, 3x D fwd+bwd, two
 clip+Adam updates) over one batch of 16 tiles per GPU already resident in HBM.  Prints ONE JSON
@@ -13,6 +18,8 @@ baseline: the oracle's plain-torch step timed on this box's host cores.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,14 +37,40 @@ import torch.nn as nn
 D_PASSES = 8 if os.environ.get('SSG_ELIDE_DEAD_D_GRADS', '0') == '1' else 9
 FLOP_PER_IMG_512 = 2 * (3 * 208.625 + D_PASSES * 24.631) * 1e9
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-# HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-# separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950):
-# profiles/r01_e_pmc_hbm_traffic_per_kernel.csv (algorithmic bytes of the same launches: tools/shapes.py).  Static: bench.py cannot run the profiler on itself.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {'conv_igemm_halo_kernel<128,128>': 764166084, 'conv_igemm_halo_kernel<128,64>': 864554588,
-                                'conv_igemm_halo_kernel<256,64>': 1648735232,
-                                'wgrad_halo_kernel<32,128>': 1406952340, 'wgrad_halo_kernel<64,64>': 3899951360,
-                                'conv_igemm_dma_kernel<128,128>': 346560165, 'conv_igemm_dma_kernel<256,64>': 1234910627,
-                                'wgrad_dma_kernel<128,128>': 828464653, 'wgrad_dma_kernel<128,64>': 4185048608}
+
+
+def _norm_symbol(name):
+    """'void (anonymous namespace)::conv_igemm_halo_kernel<128, 128, 2, 2>(ConvArgs)' -> 'conv_igemm_halo_kernel<128,128,2,2>'."""
+    name = name.split('::')[-1].split('(')[0]
+    return name.replace(' ', '')
+
+
+def pmc_traffic_table():
+    """HBM bytes per launch per kernel symbol from the newest tracked PMC summary (profiles/rNN_*pmc_hbm_traffic_per_kernel.csv:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950; aggregated by tools/pmc_traffic.py).  bench.py cannot run the profiler on itself, so the table is read from the
+    tracked file by kernel symbol; tests/test_host_logic.py fails when a dispatchable MFMA kernel has no row."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_*pmc_hbm_traffic_per_kernel.csv')))
+    if not files:
+        return None, {}
+    table = {}
+    for row in csv.DictReader(open(files[-1])):
+        table[_norm_symbol(row['kernel'])] = int(row['hbm_bytes_per_launch_corrected'])
+    return os.path.relpath(files[-1], ROOT), table
+
+
+def pmc_traffic_for(label, table):
+    """`label` is ops._CONV_LABELS / _WGRAD_LABELS style ('conv_igemm_halo_kernel<128,128>'): match the symbol whose template
+    argument list starts with the label's."""
+    if label in table:
+        return table[label]
+    stem = label.rstrip('>')
+    for k, v in table.items():
+        if k.startswith(stem + ',') or k.startswith(stem + '>'):
+            return v
+    return None
 
 
 def measured_ceilings(S, dev):
@@ -106,6 +139,61 @@ def cpu_baseline(seconds_budget=30.0):
             'sample': '%d timed G+D steps (after 1 warm-up) on 1x3x512x512, fp32, torch %d threads' % (n, cores)}
 
 
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def launch_ranks(n, argv):
+    """Parent of an N-rank run: start `python -m torch.distributed.run` as a CHILD (this process has not touched HIP and
+    never will), let the ranks inherit stdout (rank 0 prints the JSON line) and return the child's exit status."""
+    env = os.environ.copy()
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # read when HSA initialises in the ranks (dmabuf IPC for RCCL)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % n,
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    print('[bench] starting %d ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def bucket_allreduce_ms(syncs, dev, reps=5):
+    """Stand-alone timing of one all-reduce per gradient bucket (the same flat buffers, same op, same communicator) after the
+    timed steps: what each bucket costs when nothing overlaps it."""
+    out = []
+    for name, sync in syncs:
+        if sync is None:
+            continue
+        for i, b in enumerate(sync.buckets):
+            dist.all_reduce(b.flat, op=dist.ReduceOp.SUM); torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                dist.all_reduce(b.flat, op=dist.ReduceOp.SUM)
+            e1.record(); torch.cuda.synchronize()
+            out.append({'bucket': '%s%d' % (name, i), 'mbytes': round(b.flat.numel() * 4 / 1e6, 1), 'ms': round(e0.elapsed_time(e1) / reps, 3)})
+    return out
+
+
+def launch_check(args):
+    """--launch-check: the launcher / rendezvous / rank bookkeeping of an N-rank run WITHOUT the GPU step (CPU rehearsal over
+    gloo: tests/test_bench_launch.py).  Prints the same JSON skeleton with value null."""
+    import ssunet_gan_amd as S
+    rank, world, local = S.dp.init_from_env()
+    if world != args.gpus:
+        print('[bench] WORLD_SIZE=%d but --gpus %d' % (world, args.gpus), file=sys.stderr)
+        return 2
+    backend = dist.get_backend() if world > 1 else None
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'metric': 'train images/sec (512^2 tiles)', 'value': None, 'unit': 'images/sec', 'n_gpus': world,
+                          'launch_check': True, 'backend': backend, 'rank_sum': float(t.item())}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -114,12 +202,39 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='tiles per GPU')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--launch-check', action='store_true', help='rendezvous only, no GPU step (CPU rehearsal of the N-rank launch)')
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # Not started by a launcher: start the ranks ourselves.  Nothing above this line has touched HIP
+        # (importing torch does not), and the child is a new process, not an exec of this one.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if world_env != args.gpus:
+        print('[bench] refusing to run: WORLD_SIZE=%d but --gpus %d (start the ranks with --nproc-per-node %d, or let '
+              'bench.py start them by running it without a launcher)' % (world_env, args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    if args.launch_check:
+        sys.exit(launch_check(args))
 
     import ssunet_gan_amd as S
     rank, world, local = S.dp.init_from_env()
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     dev = torch.device('cuda', torch.cuda.current_device())
+    backend = None
+    if world > 1:
+        backend = dist.get_backend()
+        if dist.get_world_size() != args.gpus:
+            print('[bench] process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus), file=sys.stderr)
+            sys.exit(2)
+        if backend != 'nccl' and os.environ.get('SSG_DIST_BACKEND') != backend:
+            print('[bench] backend is %r, not RCCL ("nccl")' % backend, file=sys.stderr)
+            sys.exit(2)
+        if backend == 'nccl' and torch.cuda.device_count() < world:
+            print('[bench] %d ranks but %d visible GPUs' % (world, torch.cuda.device_count()), file=sys.stderr)
+            sys.exit(2)
 
     torch.manual_seed(41)                                          # train_seg_gan.py:35-36
     G = S.models_seg_gan.Generator(dict(arch='UNet_R_SS_v2', num_classes=3, input_channels=3, deep_supervision=False))
@@ -163,10 +278,16 @@ def main():
     dt = time.perf_counter() - t0
     prof, S.ops.PROFILE = S.ops.PROFILE, None
     note('timed %d steps: %.1f ms/step' % (args.steps, dt / args.steps * 1e3))
+    devices = [torch.cuda.current_device()]
+    buckets = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        ids = [None] * world
+        dist.all_gather_object(ids, (rank, torch.cuda.current_device(), os.environ.get('LOCAL_RANK')))
+        devices = [d for _, d, _ in sorted(ids)]
+        buckets = bucket_allreduce_ms((('G', sync_g), ('D', sync_d)), dev)
 
     if rank == 0:
         imgs = args.batch * world * args.steps
@@ -182,9 +303,13 @@ def main():
         if dom:
             label, (fl, tt, cnt) = dom
             ach = fl / tt / 1e12
+            src, table = pmc_traffic_table()
+            traffic = pmc_traffic_for(label, table)
+            if traffic is None:
+                note('WARNING: no PMC traffic row for the dominant kernel %s in %s' % (label, src))
             roof = {'bound': 'mfma', 'kernel': label, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    'traffic': PMC_TRAFFIC_BYTES_PER_LAUNCH.get(label),
+                    'traffic': traffic, 'traffic_source': src,
                     'launches': cnt, 'avg_launch_ms': round(tt / cnt * 1e3, 4),
                     'all_mfma_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'time_frac_of_step': round(v[1] / dt, 4),
                                              'launches': v[2]} for k, v in sorted(agg.items())},
@@ -199,15 +324,19 @@ def main():
                        'global_batch': args.batch * world, 'tile': args.size,
                        'parallelism': 'dp%d%s' % (world, ' (RCCL grad all-reduce + sync-BN)' if world > 1 else ''),
                        'dead_d_param_grads_of_g_step': 'computed' if D_PASSES == 9 else 'not computed (zeroed unread in the reference, train_seg_gan.py:225)'},
+            'backend': backend, 'devices': devices,
             'loss': round(float(out[0]), 6), 'iou': round(float(out[1]), 6), 'dice': round(float(out[2]), 6),
             'roofline': roof,
         }
+        if buckets is not None:
+            line['grad_bucket_allreduce'] = buckets
         if world == 1:
             line['measured_ceilings'] = measured_ceilings(S, dev)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

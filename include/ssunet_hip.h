@@ -156,9 +156,12 @@ int ssg_nhwc_to_nchw_f32(const float* src, int ld, int N, int C, int H, int W, f
  *            var_mode 0: invstd = 1/sqrt(var_b + eps)        (torch, batchnorm.py:52-55)
  *            var_mode 1: invstd = clamp(var_b, eps)^-1/2     (sync branch, batchnorm.py:127)
  *   apply  : y = x*scale[c] + shift[c] (+res) -> act
+ * Sync-BN with unequal local batches: with_count != 0 makes stage 1 also write sums[2C] = P (so `sums` holds 2C+1
+ * doubles and the rank's pixel count is all-reduced with the sums); stage 2 and the backward apply take the count from
+ * sums[2C] when their `count` argument is <= 0.
  */
 int64_t ssg_bn_workspace_bytes(int64_t P, int C);
-int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, void* ws, void* stream);
+int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, int with_count, void* ws, void* stream);
 int ssg_bn_finalize_f32(const double* sums, double count, int C, const float* weight, const float* bias,
                         float eps, float momentum, int var_mode,
                         float* running_mean, float* running_var,
@@ -173,7 +176,7 @@ int ssg_bn_apply_f32(const float* x, int64_t P, int C, int ld, const float* scal
 int ssg_bn_bwd_reduce_f32(const float* x, const float* y, const float* dy, int64_t P, int C,
                           int ldx, int ldy, int lddy, const float* mean, const float* invstd,
                           const float* scale, const float* shift,
-                          int act, float slope, double* sums, void* ws, void* stream);
+                          int act, float slope, double* sums, int with_count, void* ws, void* stream);
 int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float* dy, int64_t P, int C,
                          int ldx, int ldy, int lddy, const float* mean, const float* invstd,
                          const float* weight, const float* scale, const float* shift,
@@ -232,13 +235,14 @@ int ssg_mask_zero_f32(const float* g, const uint8_t* mask, int64_t n, float* out
  *   stats[n*3 + {0,1,2}] = per-sample (sum p*t, sum p, sum t)  (kept for backward)
  *   stats[3N + {0..4}]   = (|pred&tgt|, |pred|tgt|, sum p*t, sum p, sum t) on channels >= mc0
  *                          (metric partial sums, all-reduced across ranks); stats holds 3N+5 doubles
- * backward: dx = g_seg * dBCEDice/dx + g_mse * dMSE/dx, g_* read from device scalars. */
+ * backward: dx = g_seg * dBCEDice/dx + g_mse * dMSE/dx + g_bce * dStableBCE/dx, g_* read from device scalars
+ * (NULL = 0); res[3..7] carry no gradient. */
 int64_t ssg_seg_loss_workspace_bytes(int N, int64_t S, int C);
 int ssg_seg_loss_fwd_f32(const float* x, int ldx, const float* t, int ldt, int N, int64_t S, int C, int mc0,
                          float* res, double* stats, void* ws, void* stream);
 int ssg_seg_loss_bwd_f32(const float* x, int ldx, const float* t, int ldt, int N, int64_t S, int C,
                          const float* res, const double* stats, const float* g_seg, const float* g_mse,
-                         float* dx, int lddx, void* stream);
+                         const float* g_bce, float* dx, int lddx, void* stream);
 /* BCEWithLogitsLoss(mean) of n logits x[i*ldx] against a constant label
  * (train_seg_gan.py:204,221-222); backward writes dx[i*lddx] and zeros the pad columns. */
 int ssg_bce_logits_const_fwd_f32(const float* x, int n, int ldx, float label, float* loss, void* stream);

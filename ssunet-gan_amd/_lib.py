@@ -69,10 +69,10 @@ SIGNATURES = {
     'ssg_nchw_to_nhwc_f32': [_P, _I, _I, _I, _I, _P, _I, _P],
     'ssg_nhwc_to_nchw_f32': [_P, _I, _I, _I, _I, _I, _P, _P],
     'ssg_bn_workspace_bytes': [_L, _I],
-    'ssg_bn_stats_f32': [_P, _L, _I, _I, _P, _P, _P],
+    'ssg_bn_stats_f32': [_P, _L, _I, _I, _P, _I, _P, _P],
     'ssg_bn_finalize_f32': [_P, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     'ssg_bn_apply_f32': [_P, _L, _I, _I, _P, _P, _P, _I, _I, _F, _P, _I, _P],
-    'ssg_bn_bwd_reduce_f32': [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P],
+    'ssg_bn_bwd_reduce_f32': [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P],
     'ssg_bn_bwd_apply_f32': [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _D, _I, _F, _P, _I, _P, _I, _P, _P, _P],
     'ssg_maxpool2x2_fwd_f32': [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     'ssg_maxpool2x2_bwd_f32': [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P],
@@ -94,7 +94,7 @@ SIGNATURES = {
     'ssg_mask_zero_f32': [_P, _P, _L, _P, _P],
     'ssg_seg_loss_workspace_bytes': [_I, _L, _I],
     'ssg_seg_loss_fwd_f32': [_P, _I, _P, _I, _I, _L, _I, _I, _P, _P, _P, _P],
-    'ssg_seg_loss_bwd_f32': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _I, _P],
+    'ssg_seg_loss_bwd_f32': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     'ssg_bce_logits_const_fwd_f32': [_P, _I, _I, _F, _P, _P],
     'ssg_bce_logits_const_bwd_f32': [_P, _I, _I, _F, _P, _P, _I, _P],
     'ssg_clamp_adam_multi_f32': [_P, _P, _P, _P, _I, _F, _D, _D, _D, _D, _D, _D, _D, _P],

@@ -56,7 +56,7 @@ class BasicBlock(nn.Module):
         cached until a parameter or running statistic changes."""
         srcs = (self.conv1.weight, self.conv2.weight, self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var,
                 self.bn2.weight, self.bn2.bias, self.bn2.running_mean, self.bn2.running_var)
-        stamp = tuple((t.data_ptr(), t._version) for t in srcs) + (ops._WEIGHT_EPOCH[0],)
+        stamp = tuple((t.data_ptr(), t._version) for t in srcs) + (ops._WEIGHT_EPOCH[0], ops._STATS_EPOCH[0])
         hit = getattr(self, '_fold_cache', None)
         if hit is not None and hit[0] == stamp:
             return hit[1]

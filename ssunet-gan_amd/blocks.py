@@ -23,7 +23,7 @@ class _BasicBlockFn(torch.autograd.Function):
         x1 = to_nhwc(x1)
         x2 = to_nhwc(x2) if x2 is not None else None
         c1 = _conv_fwd_impl(x1, x2, w1, None, stride, 1, ACT_NONE, 0.0)
-        y1, st1, world = _bn_fwd_impl(c1, g1, b1, rm1, rv1, None, eps1, mom1, ACT_RELU, 0.0, var_mode, group)
+        y1, st1, cnt1 = _bn_fwd_impl(c1, g1, b1, rm1, rv1, None, eps1, mom1, ACT_RELU, 0.0, var_mode, group)
         c2 = _conv_fwd_impl(y1, None, w2, None, 1, 1, ACT_NONE, 0.0)
         if wsc is not None:
             sc = _conv_fwd_impl(x1, x2, wsc, None, stride, 0, ACT_NONE, 0.0)
@@ -31,25 +31,25 @@ class _BasicBlockFn(torch.autograd.Function):
             if x2 is not None:
                 raise ValueError('identity shortcut with a two-tensor input')
             sc = x1
-        out, st2, _ = _bn_fwd_impl(c2, g2, b2, rm2, rv2, sc, eps2, mom2, ACT_RELU, 0.0, var_mode, group)
+        out, st2, cnt2 = _bn_fwd_impl(c2, g2, b2, rm2, rv2, sc, eps2, mom2, ACT_RELU, 0.0, var_mode, group)
         ctx.save_for_backward(x1, x2, c1, y1, c2, out, w1, g1, w2, g2, wsc, st1, st2)
-        ctx.cfg = (stride, group, world)
+        ctx.cfg = (stride, group, cnt1, cnt2)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
         x1, x2, c1, y1, c2, out, w1, g1, w2, g2, wsc, st1, st2 = ctx.saved_tensors
-        stride, group, world = ctx.cfg
+        stride, group, cnt1, cnt2 = ctx.cfg
         dout = to_nhwc(dout)
         n, ca, h, w = x1.shape
         cb = x2.shape[1] if x2 is not None else 0
         need_x1, need_x2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
         # bn2 backward; dres = dout masked by the final ReLU = gradient of the shortcut branch
-        dc2, g, dg2, db2 = _bn_bwd_impl(c2, out, dout, g2, st2, ACT_RELU, 0.0, group, world, want_dres=True)
+        dc2, g, dg2, db2 = _bn_bwd_impl(c2, out, dout, g2, st2, ACT_RELU, 0.0, group, cnt2, want_dres=True)
         dw2 = _conv_wgrad_impl(y1, None, dc2, w2.shape, 1, 1)
         dy1 = _conv_dgrad_impl(dc2, w2, 1, 1, y1.shape[2], y1.shape[3], 0, y1.shape[1])
-        dc1, _, dg1, db1 = _bn_bwd_impl(c1, y1, dy1, g1, st1, ACT_RELU, 0.0, group, world, want_dres=False, had_res=False)
+        dc1, _, dg1, db1 = _bn_bwd_impl(c1, y1, dy1, g1, st1, ACT_RELU, 0.0, group, cnt1, want_dres=False, had_res=False)
         dw1 = _conv_wgrad_impl(x1, x2, dc1, w1.shape, stride, 1)
         dwsc = _conv_wgrad_impl(x1, x2, g, wsc.shape, stride, 0) if wsc is not None else None
         dx1 = dx2 = None

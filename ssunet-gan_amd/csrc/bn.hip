@@ -147,7 +147,8 @@ __global__ __launch_bounds__(RED_BLOCK) void modulate_bwd_sums_kernel(
 // reproducible), 1/32 of the serial chain of a one-thread-per-channel loop.
 constexpr int FIN_LANES = 32;
 __global__ __launch_bounds__(32 * FIN_LANES) void col_reduce_final_kernel(const double* __restrict__ part, int parts, int C, int C4,
-                                                                          double* __restrict__ sums, float* __restrict__ fsum) {
+                                                                          double* __restrict__ sums, float* __restrict__ fsum,
+                                                                          double count_out) {
   __shared__ double red[2][FIN_LANES][32];
   const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -165,14 +166,17 @@ __global__ __launch_bounds__(32 * FIN_LANES) void col_reduce_final_kernel(const 
     if (sums) { sums[c] = t1; sums[C + c] = t2; }
     if (fsum) fsum[c] = (float)t1;
   }
+  // sync-BN: this rank's pixel count rides the vector that is all-reduced (ranks may hold different local batches)
+  if (sums && count_out > 0 && blockIdx.x == 0 && threadIdx.x == 0) sums[2 * C] = count_out;
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C, const float* __restrict__ weight,
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count_arg, int C, const float* __restrict__ weight,
                                    const float* __restrict__ bias, float eps, float momentum, int var_mode,
                                    float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                                    float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  const double count = count_arg > 0 ? count_arg : sums[2 * C];
   const double m = sums[c] / count;
   double var = sums[C + c] / count - m * m;
   if (var < 0) var = 0;
@@ -213,9 +217,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, long long P, int C, int ldx,
     int ldy, int lddy, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ weight,
     const float* __restrict__ scale, const float* __restrict__ shift,
-    const double* __restrict__ sums, double count, int act, float slope, float* __restrict__ dx, int lddx,
+    const double* __restrict__ sums, double count_arg, int act, float slope, float* __restrict__ dx, int lddx,
     float* __restrict__ dres, int lddres, float* __restrict__ dweight, float* __restrict__ dbias) {
   const int CQ = C / 4;
+  const double count = count_arg > 0 ? count_arg : sums[2 * C];
   const long long total = P * CQ;
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -271,14 +276,14 @@ template <int MODE>
 int run_reduce(const float* x, const float* y, const float* dy, long long P, int C, int ldx, int ldy, int lddy,
                const float* scale, const float* shift,
                const float* mean, const float* invstd, int act, float slope, double* sums, float* fsum, void* ws,
-               hipStream_t st) {
+               hipStream_t st, double count_out = 0.0) {
   const RedGeom g = red_geom(P, C);
   const int C4 = 4 * ((C + 3) / 4);
   double* part = (double*)ws;
   hipLaunchKernelGGL((col_reduce_kernel<MODE>), dim3((unsigned)g.parts, (unsigned)g.groups), dim3(RED_BLOCK), 0, st, x, y, dy,
                      P, C, ldx, ldy, lddy, mean, invstd, scale, shift, act, slope, g.TQ, g.PR, g.rows_per_part, part);
   SSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C4, sums, fsum);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C4, sums, fsum, count_out);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -290,10 +295,11 @@ extern "C" int64_t ssg_bn_workspace_bytes(int64_t P, int C) {
   return (int64_t)g.parts * 2 * 4 * ((C + 3) / 4) * (int64_t)sizeof(double);
 }
 
-extern "C" int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, void* ws, void* stream) {
+extern "C" int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, int with_count, void* ws, void* stream) {
   SSG_REQUIRE(x && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_stats: bad args");
   SSG_REQUIRE(ld % 4 == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN, "bn_stats: alignment");
-  return run_reduce<0>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, sums, nullptr, ws, (hipStream_t)stream);
+  return run_reduce<0>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, sums, nullptr, ws, (hipStream_t)stream,
+                       with_count ? (double)P : 0.0);
 }
 
 extern "C" int ssg_channel_sum_f32(const float* x, int64_t P, int C, int ld, float* out, void* ws, void* stream) {
@@ -305,7 +311,7 @@ extern "C" int ssg_channel_sum_f32(const float* x, int64_t P, int C, int ld, flo
 extern "C" int ssg_bn_finalize_f32(const double* sums, double count, int C, const float* weight, const float* bias,
                                    float eps, float momentum, int var_mode, float* running_mean, float* running_var,
                                    float* mean, float* invstd, float* scale, float* shift, void* stream) {
-  SSG_REQUIRE(sums && mean && invstd && scale && shift && C > 0 && count > 0, SSG_EINVAL, "bn_finalize: bad args");
+  SSG_REQUIRE(sums && mean && invstd && scale && shift && C > 0, SSG_EINVAL, "bn_finalize: bad args");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, (hipStream_t)stream, sums, count, C,
                      weight, bias, eps, momentum, var_mode, running_mean, running_var, mean, invstd, scale, shift);
   SSG_LAUNCH_CHECK();
@@ -324,11 +330,12 @@ extern "C" int ssg_bn_apply_f32(const float* x, int64_t P, int C, int ld, const 
 
 extern "C" int ssg_bn_bwd_reduce_f32(const float* x, const float* y, const float* dy, int64_t P, int C, int ldx, int ldy,
                                      int lddy, const float* mean, const float* invstd, const float* scale, const float* shift,
-                                     int act, float slope, double* sums, void* ws, void* stream) {
+                                     int act, float slope, double* sums, int with_count, void* ws, void* stream) {
   SSG_REQUIRE(x && dy && mean && invstd && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_bwd_reduce: bad args");
   SSG_REQUIRE(act == SSG_ACT_NONE || y || (scale && shift), SSG_EINVAL, "bn_bwd_reduce: activation mask needs y or (scale, shift)");
   SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_reduce: alignment");
-  return run_reduce<1>(x, y, dy, P, C, ldx, ldy, lddy, scale, shift, mean, invstd, act, slope, sums, nullptr, ws, (hipStream_t)stream);
+  return run_reduce<1>(x, y, dy, P, C, ldx, ldy, lddy, scale, shift, mean, invstd, act, slope, sums, nullptr, ws, (hipStream_t)stream,
+                       with_count ? (double)P : 0.0);
 }
 
 extern "C" int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float* dy, int64_t P, int C, int ldx, int ldy,
@@ -336,7 +343,7 @@ extern "C" int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float*
                                     const float* scale, const float* shift, const double* sums,
                                     double count, int act, float slope, float* dx, int lddx, float* dres, int lddres,
                                     float* dweight, float* dbias, void* stream) {
-  SSG_REQUIRE(x && dy && mean && invstd && sums && P > 0 && C > 0 && count > 0, SSG_EINVAL, "bn_bwd_apply: bad args");
+  SSG_REQUIRE(x && dy && mean && invstd && sums && P > 0 && C > 0, SSG_EINVAL, "bn_bwd_apply: bad args");
   SSG_REQUIRE(act == SSG_ACT_NONE || y || (scale && shift), SSG_EINVAL, "bn_bwd_apply: activation mask needs y or (scale, shift)");
   SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_apply: alignment");
   SSG_REQUIRE(C <= 4096, SSG_EINVAL, "bn_bwd_apply: C > 4096");
@@ -362,7 +369,7 @@ extern "C" int ssg_spade_modulate_bwd_sums_f32(const float* x, int ldx, const fl
                      (long long)P, C, dx, lddx, dgb, lddgb, g.TQ, g.PR, g.rows_per_part, part);
   SSG_LAUNCH_CHECK();
   // sums[0:C] = sum dgamma, sums[C:2C] = sum dbeta (ssg_bn_workspace_bytes(P, C) bytes of workspace)
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C, sums, nullptr);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C, sums, nullptr, 0.0);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -136,10 +136,12 @@ __global__ __launch_bounds__(1024) void seg_loss_final_kernel(const double* __re
 __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ t, int ldt,
                                                            int N, long long S, int C, const float* __restrict__ res,
                                                            const double* __restrict__ stats, const float* __restrict__ g_seg,
-                                                           const float* __restrict__ g_mse, float* __restrict__ dx, int lddx) {
+                                                           const float* __restrict__ g_mse, const float* __restrict__ g_bce,
+                                                           float* __restrict__ dx, int lddx) {
   const long long total = (long long)N * S;
   const double numel = (double)N * (double)S * (double)C;
   const float gs = g_seg ? *g_seg : 0.f, gm = g_mse ? *g_mse : 0.f;
+  const float gb = g_bce ? (float)((double)*g_bce / numel) : 0.f;       // res[2] = StableBCELoss alone (losses.py:130-136)
   const bool finite = res[6] != 0.f;
   const float k_bce = finite ? (float)(0.5 / numel) : 0.f;
   const float k_dice = finite ? 1.f : 2.f;
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
         // d(1 - mean_n dice_n)/dp = -(1/N) * (2 t U - (2I + s)) / U^2
         const float ddice = -(2.f * tv * invU - ratio) / (float)N;
         g = gs * (k_bce * (pv - tv) + k_dice * ddice * pv * (1.f - pv)) + gm * k_mse * (xv - tv);
+        if (gb != 0.f) g += gb * (pv - tv);
       }
       dp[c] = g;
     }
@@ -209,12 +212,13 @@ extern "C" int ssg_seg_loss_fwd_f32(const float* x, int ldx, const float* t, int
 }
 
 extern "C" int ssg_seg_loss_bwd_f32(const float* x, int ldx, const float* t, int ldt, int N, int64_t S, int C, const float* res,
-                                    const double* stats, const float* g_seg, const float* g_mse, float* dx, int lddx, void* stream) {
+                                    const double* stats, const float* g_seg, const float* g_mse, const float* g_bce, float* dx, int lddx,
+                                    void* stream) {
   SSG_REQUIRE(x && t && res && stats && dx && N > 0 && S > 0 && C > 0 && lddx >= C, SSG_EINVAL, "seg_loss_bwd: bad args");
   long long grid = ((long long)N * S + 255) / 256;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, ldx, t, ldt, N, (long long)S, C, res,
-                     stats, g_seg, g_mse, dx, lddx);
+                     stats, g_seg, g_mse, g_bce, dx, lddx);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -23,8 +23,14 @@ import torch.nn as nn
 BUCKET_BYTES = 64 << 20       # xGMI is point-to-point: few, large messages keep every link busy
 
 
+# SSG_DIST_FORCE=1: treat a world of ONE rank as distributed too, so that every collective of the data-parallel path
+# (bucketed all-reduce, sync-BN sums, metric sums) really goes through the backend.  A 1-GPU box can run RCCL only at
+# world size 1 (two ranks on one device are refused), so this is how the RCCL calls are rehearsed there.
+FORCE = os.environ.get('SSG_DIST_FORCE', '0') == '1'
+
+
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
 
 
 def init_from_env(backend=None):
@@ -32,12 +38,14 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # read by the HSA runtime when it initialises (first HIP call below): dmabuf IPC, which RCCL needs on this driver.
+    # A launcher normally exports it already; this covers a bare `python script.py` rank.
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if torch.cuda.is_available():
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
             # RCCL ('nccl') on GPUs; SSG_DIST_BACKEND=gloo lets several ranks share one GPU in rehearsals
             backend = os.environ.get('SSG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
@@ -65,6 +73,8 @@ def broadcast_parameters(module, src=0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+    from . import ops
+    ops.bump_weight_epoch()          # written through .data: version counters did not move, packed/folded caches must
 
 
 class _Bucket(object):
@@ -77,6 +87,7 @@ class GradSync(object):
     def __init__(self, module, group=None, bucket_bytes=BUCKET_BYTES):
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.reduce = is_dist()
         self.active = False
         self.buckets = []
         self._where = {}
@@ -92,7 +103,7 @@ class GradSync(object):
             self._make_bucket(cur)
         for p in params:
             p.register_post_accumulate_grad_hook(self._hook)
-        backend = dist.get_backend(group) if self.world > 1 else None
+        backend = dist.get_backend(group) if self.reduce else None
         self._avg_native = backend == 'nccl'
 
     def _make_bucket(self, params):
@@ -119,7 +130,7 @@ class GradSync(object):
         self.active = True
 
     def _launch(self, b):
-        if self.world <= 1:
+        if not self.reduce:
             return
         if self._avg_native:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
@@ -159,6 +170,20 @@ def grad_syncs(generator, discriminator):
     if key not in _SYNCS:
         _SYNCS[key] = (GradSync(generator), GradSync(discriminator))
     return _SYNCS[key]
+
+
+def grad_sync(model):
+    """One cached GradSync per module (stage-1 trainer: train() is called once per epoch; a fresh GradSync per call would
+    leak a model-sized bucket set and one dead hook per parameter each epoch)."""
+    if not is_dist():
+        return None
+    key = id(model)
+    hit = _SYNCS.get(key)
+    if hit is None or hit[0]() is not model:
+        import weakref
+        hit = (weakref.ref(model), GradSync(model))
+        _SYNCS[key] = hit
+    return hit[1]
 
 
 def reduce_metric_sums(sums, group=None):

@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from . import ops
 
-__all__ = ['BCEDiceLoss', 'StableBCELoss']
+__all__ = ['BCEDiceLoss', 'LovaszHingeLoss']          # as the reference's losses.__all__ (losses.py:14)
 
 
 class StableBCELoss(nn.Module):
@@ -20,3 +20,12 @@ class BCEDiceLoss(nn.Module):
 
     def forward(self, input, target):
         return ops.seg_loss(input, target)[0]
+
+
+class LovaszHingeLoss(nn.Module):
+    """losses.py:222-233.  Exported by the reference's losses.__all__ (so it is a legal config['loss'] name), but the only
+    config selects BCEDiceLoss (config_v1.json:26) and the Lovasz family is off the hot path: there is
+    no HIP kernel for it, and no CPU fallback by design -- constructing it is allowed, calling it raises."""
+
+    def forward(self, input, target):
+        raise NotImplementedError('LovaszHingeLoss has no HIP path in ssunet-gan_amd (off the hot path; use BCEDiceLoss)')

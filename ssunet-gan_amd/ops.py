@@ -452,58 +452,73 @@ def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
 
 
 # ----------------------------------------------------------------------------- batch norm (+residual, +activation)
-def _allreduce_sums(sums, group):
-    if group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-        return dist.get_world_size(group)
-    return 1
+def _synced(group):
+    """True when batch-norm sums have to travel: a process group is attached and the job is distributed
+    (world > 1, or SSG_DIST_FORCE=1 -- dp.FORCE -- which sends a single rank's collectives through the backend too)."""
+    if group is None or not (dist.is_available() and dist.is_initialized()):
+        return False
+    from . import dp
+    return dist.get_world_size(group) > 1 or dp.FORCE
+
+
+# bumped whenever a training-mode batch norm rewrites running statistics through raw pointers (tensor version counters do
+# not see that): part of the stamp of every eval-mode BN-fold cache (archs.BasicBlock._folded)
+_STATS_EPOCH = [0]
 
 
 def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group):
-    """stats -> (all-reduce) -> finalize -> apply.  Returns (y, stats[4,C], world)."""
+    """stats -> (all-reduce) -> finalize -> apply.  Returns (y, stats[4,C], count): `count` is None for a local batch norm
+    and, when synchronised, the fp64[1] device tensor holding the all-reduced pixel count (ranks may hold unequal batches:
+    the count travels with the sums instead of being assumed to be p * world)."""
     n, c, h, w = x.shape
     if c % 4:
         raise ValueError('batch_norm: C %% 4 != 0 unsupported (C=%d)' % c)
     p = n * h * w
     dev = x.device
+    synced = _synced(group)
     ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
-    sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
-    call('ssg_bn_stats_f32', ptr(x), p, c, _ld(x), ptr(sums), ptr(ws), stream_ptr())
-    world = _allreduce_sums(sums, group)
+    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+    call('ssg_bn_stats_f32', ptr(x), p, c, _ld(x), ptr(sums), int(synced), ptr(ws), stream_ptr())
+    if synced:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     stats = torch.empty((4, c), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
-    call('ssg_bn_finalize_f32', ptr(sums), float(p * world), c, ptr(weight), ptr(bias), eps, momentum, var_mode,
+    call('ssg_bn_finalize_f32', ptr(sums), 0.0 if synced else float(p), c, ptr(weight), ptr(bias), eps, momentum, var_mode,
          ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), stream_ptr())
+    if running_mean is not None or running_var is not None:
+        _STATS_EPOCH[0] += 1
     y = new_nhwc(n, c, h, w, dev)
     call('ssg_bn_apply_f32', ptr(x), p, c, _ld(x), ptr(stats[2]), ptr(stats[3]), ptr(res), _ld(res) if res is not None else 0,
          act, slope, ptr(y), _ld(y), stream_ptr())
-    return y, stats, world
+    return y, stats, (sums[2 * c:] if synced else None)
 
 
-def _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, want_dres, want_dx=True, had_res=True):
+def _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, count, want_dres, want_dx=True, had_res=True):
     """Returns (dx, dres, dweight, dbias).  The activation mask is read from y, or -- when the forward had no
-    residual (`had_res=False`) -- recomputed from x with the forward's (scale, shift): y is then not read."""
+    residual (`had_res=False`) -- recomputed from x with the forward's (scale, shift): y is then not read.
+    `count`: what _bn_fwd_impl returned (None = local batch norm)."""
     n, c, h, w = x.shape
     p = n * h * w
     dev = x.device
     if act == ACT_NONE or not had_res:
         y = None
+    synced = count is not None
     ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
-    sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
     call('ssg_bn_bwd_reduce_f32', ptr(x), ptr(y), ptr(dy), p, c, _ld(x), _ld(y) if y is not None else 0, _ld(dy),
-         ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), act, slope, ptr(sums), ptr(ws), stream_ptr())
+         ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), act, slope, ptr(sums), int(synced), ptr(ws), stream_ptr())
     # local (un-reduced) sums are this rank's weight/bias gradients; data-parallel all-reduces them later
-    synced = group is not None and world > 1
     local = sums.clone() if synced else sums
-    _allreduce_sums(sums, group)
+    if synced:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     dwb = torch.empty((2, c), dtype=torch.float32, device=dev)
     dx = new_nhwc(n, c, h, w, dev) if want_dx else None
     dres = new_nhwc(n, c, h, w, dev) if want_dres else None
     call('ssg_bn_bwd_apply_f32', ptr(x), ptr(y), ptr(dy), p, c, _ld(x), _ld(y) if y is not None else 0, _ld(dy),
-         ptr(stats[0]), ptr(stats[1]), ptr(weight), ptr(stats[2]), ptr(stats[3]), ptr(sums), float(p * world), act, slope,
+         ptr(stats[0]), ptr(stats[1]), ptr(weight), ptr(stats[2]), ptr(stats[3]), ptr(sums), 0.0 if synced else float(p), act, slope,
          ptr(dx), _ld(dx) if dx is not None else 0, ptr(dres), _ld(dres) if dres is not None else 0,
          ptr(dwb[0]), ptr(dwb[1]), stream_ptr())
     if synced:
-        dwb = torch.stack([local[c:], local[:c]]).float()
+        dwb = torch.stack([local[c:2 * c], local[:c]]).float()
     return dx, dres, dwb[0], dwb[1]
 
 
@@ -529,28 +544,28 @@ class _BatchNormAct(torch.autograd.Function):
             wp = torch.nn.functional.pad(weight.detach(), (0, c4 - c)); bp = torch.nn.functional.pad(bias.detach(), (0, c4 - c))
             rm = torch.nn.functional.pad(running_mean, (0, c4 - c)) if running_mean is not None else None
             rv = torch.nn.functional.pad(running_var, (0, c4 - c), value=1.0) if running_var is not None else None
-            y, stats, world = _bn_fwd_impl(x, wp, bp, rm, rv, res, eps, momentum, act, slope, var_mode, group)
+            y, stats, cnt = _bn_fwd_impl(x, wp, bp, rm, rv, res, eps, momentum, act, slope, var_mode, group)
             if running_mean is not None:
                 running_mean.copy_(rm[:c])
             if running_var is not None:
                 running_var.copy_(rv[:c])
             weight = wp
         else:
-            y, stats, world = _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group)
+            y, stats, cnt = _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group)
         ctx.save_for_backward(x, y if (act != ACT_NONE and res is not None) else None, weight, stats)   # no residual: mask is recomputed
-        ctx.cfg = (act, slope, group, world, res is not None, c)
+        ctx.cfg = (act, slope, group, cnt, res is not None, c)
         return _relabel(y, c) if c4 != c else y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, y, weight, stats = ctx.saved_tensors
-        act, slope, group, world, has_res, c = ctx.cfg
+        act, slope, group, cnt, has_res, c = ctx.cfg
         dy = to_nhwc(dy)
         c4 = x.shape[1]
         if c4 != c:
             dy = _relabel(dy, c4)
-        dx, dres, dw, db = _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, world, has_res and ctx.needs_input_grad[5],
+        dx, dres, dw, db = _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, cnt, has_res and ctx.needs_input_grad[5],
                                         had_res=has_res)
         if c4 != c:
             dx = _relabel(dx, c)
@@ -769,7 +784,8 @@ def spade_modulate(x, gb):
 # ----------------------------------------------------------------------------- losses
 class _SegLoss(torch.autograd.Function):
     """Fused BCEDiceLoss + MSELoss + IoU/Dice metrics.  Returns a float32[8] tensor `res`
-    (layout in include/ssunet_hip.h); gradients flow from res[0] (BCEDice) and res[1] (MSE)."""
+    (layout in include/ssunet_hip.h); gradients flow from res[0] (BCEDice), res[1] (MSE) and res[2] (StableBCE);
+    res[3:] are metrics (their incoming gradient is ignored, as the reference computes them in numpy)."""
 
     @staticmethod
     def forward(ctx, x, t, mc0):
@@ -793,7 +809,7 @@ class _SegLoss(torch.autograd.Function):
         g = g.contiguous()
         dx = new_nhwc(n, c, h, w, x.device)
         call('ssg_seg_loss_bwd_f32', ptr(x), _ld(x), ptr(t), _ld(t), n, h * w, c, ptr(res), ptr(stats),
-             C.c_void_p(g.data_ptr()), C.c_void_p(g.data_ptr() + 4), ptr(dx), _ld(dx), stream_ptr())
+             C.c_void_p(g.data_ptr()), C.c_void_p(g.data_ptr() + 4), C.c_void_p(g.data_ptr() + 8), ptr(dx), _ld(dx), stream_ptr())
         return dx, None, None
 
 

@@ -39,7 +39,7 @@ def train(epoch, config, train_loader, model, criterion, optimizer, cnn_optimize
     clip = float(config['clip'])
     print('learning rate {:d}: {:f}'.format(epoch, optimizer.param_groups[0]['lr']))
     num_class = int(config['num_classes'])
-    sync = dp.GradSync(model) if dp.is_dist() else None
+    sync = dp.grad_sync(model)
     params = [p for p in model.parameters()]
     for ori_img, input, target, targets, _ in train_loader:
         input = input.cuda(non_blocking=True)
