@@ -401,6 +401,10 @@ def main():
         gen_step(mods, 'step_n2_64', 2, 64, 64, steps=2)
     if a.only in (None, 'step256'):
         gen_step(mods, 'step_n4_256', 4, 256, 256, steps=1, keep_logits=False)
+    if a.only == 'step512':
+        # BASELINE config 2 at full size (16 x 3 x 512 x 512): ~45 GB RSS and a few minutes of the reference on 8 cores, so
+        # it only runs on request (`--only step512`); logits are stored down-sampled 8x (as step256) + digests + scalars.
+        gen_step(mods, 'step_n16_512', 16, 512, 512, steps=1, keep_logits=False)
 
 
 if __name__ == '__main__':

@@ -18,6 +18,70 @@ NB_FILTER = (64, 128, 256, 384, 512, 768)          # archs.py:568
 SS_SCALE = 16                                      # archs.py:575
 
 
+# ----------------------------------------------------------------------------- activation pattern (test aid)
+class ActivationPattern(object):
+    """The network is piecewise linear in its ReLU / LeakyReLU masks and max-pool argmax choices.  Parity tests use this to
+    separate the two things that can differ between two fp32 implementations: (a) WHICH linear piece a near-tie lands on
+    (|pre-activation| or top-2 pool gap below fp32 noise) and (b) the arithmetic on a given piece.
+      mode 'record': the forward runs normally and appends, in call order, ('act', pre-activation) / ('pool', input, plane index);
+      mode 'impose': items is a list of bool masks (act) / int64 window positions 0..3 (pool) in the same call order, and the
+                     forward uses THEM instead of its own comparisons (so an fp64 run evaluates exactly the piece another
+                     implementation was on).
+    With PATTERN = None (the default) every op is the stock torch op: fixtures and the CPU baseline are unaffected."""
+
+    def __init__(self, mode, items=None):
+        assert mode in ('record', 'impose')
+        self.mode, self.items, self.pos = mode, (items if items is not None else []), 0
+
+
+PATTERN = None
+
+
+def _act(x, slope=0.0):
+    P = PATTERN
+    if P is None or P.mode == 'record':
+        if P is not None:
+            P.items.append(('act', x.detach().clone()))
+        return F.relu(x) if slope == 0.0 else F.leaky_relu(x, slope)
+    m = P.items[P.pos]; P.pos += 1
+    assert m.shape == x.shape, 'activation pattern out of step: %s vs %s' % (tuple(m.shape), tuple(x.shape))
+    return torch.where(m, x, x * slope)
+
+
+class _ReLU(nn.Module):
+    def forward(self, x):
+        return _act(x)
+
+
+class _LeakyReLU(nn.Module):
+    def __init__(self, slope):
+        super().__init__()
+        self.negative_slope = slope
+
+    def forward(self, x):
+        return _act(x, self.negative_slope)
+
+
+class _MaxPoolIdx(nn.Module):
+    """nn.MaxPool2d(2, 2, return_indices=True) (archs.py:571)."""
+
+    def forward(self, x):
+        P = PATTERN
+        if P is None or P.mode == 'record':
+            y, idx = F.max_pool2d(x, 2, 2, return_indices=True)
+            if P is not None:
+                P.items.append(('pool', x.detach().clone(), idx.clone()))
+            return y, idx
+        win = P.items[P.pos]; P.pos += 1
+        n, c, h, w = x.shape
+        assert win.shape == (n, c, h // 2, w // 2)
+        xs = x.unfold(2, 2, 2).unfold(3, 2, 2).reshape(n, c, h // 2, w // 2, 4)
+        y = xs.gather(-1, win.unsqueeze(-1)).squeeze(-1)
+        oy = torch.arange(h // 2).view(1, 1, -1, 1); ox = torch.arange(w // 2).view(1, 1, 1, -1)
+        idx = (2 * oy + win // 2) * w + 2 * ox + win % 2
+        return y, idx
+
+
 # ----------------------------------------------------------------------------- blocks
 class ResBlockCPU(nn.Module):
     """archs.py:205-241 (BasicBlock): relu(bn1(conv3x3)) -> bn2(conv3x3) -> += 1x1 shortcut
@@ -34,9 +98,9 @@ class ResBlockCPU(nn.Module):
             self.shortcut = nn.Sequential(nn.Conv2d(cin, cout, 1, 1, bias=False))
 
     def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
+        y = _act(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
-        return F.relu(y + self.shortcut(x))
+        return _act(y + self.shortcut(x))
 
 
 class SelfSpadeCPU(nn.Module):
@@ -48,7 +112,7 @@ class SelfSpadeCPU(nn.Module):
         super().__init__()
         self.param_free_norm = nn.BatchNorm2d(norm_nc, affine=False)   # :81 ('batch')
         nh = int(max(nhidden, 4))                                      # :88
-        self.mlp_shared = nn.Sequential(nn.Conv2d(label_nc, nh, 3, padding=1), nn.ReLU())
+        self.mlp_shared = nn.Sequential(nn.Conv2d(label_nc, nh, 3, padding=1), _ReLU())
         self.x2map = nn.Conv2d(norm_nc, label_nc, 3, padding=1)
         self.mlp_gamma = nn.Conv2d(nh, norm_nc, 3, padding=1)
         self.mlp_beta = nn.Conv2d(nh, norm_nc, 3, padding=1)
@@ -66,7 +130,7 @@ class UNetRSSv2CPU(nn.Module):
         super().__init__()
         f = NB_FILTER
         sm = num_classes
-        self.pool = nn.MaxPool2d(2, 2, return_indices=True)
+        self.pool = _MaxPoolIdx()
         self.unpool = nn.MaxUnpool2d(2, stride=2)
         self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
 
@@ -136,7 +200,7 @@ class _ConvBlockCPU(nn.Module):
         layers = [nn.Conv2d(cin, cout, k, stride, k // 2)]
         if bn:
             layers.append(nn.BatchNorm2d(cout))
-        layers.append(nn.LeakyReLU(0.2))
+        layers.append(_LeakyReLU(0.2))
         self.conv_block = nn.Sequential(*layers)
 
     def forward(self, x):
@@ -157,7 +221,7 @@ class DiscriminatorCPU(nn.Module):
         self.conv_blocks = nn.Sequential(*blocks)
         self.adaptive_pool = nn.AdaptiveAvgPool2d((6, 6))
         self.fc1 = nn.Linear(cin * 36, fc_size)
-        self.leaky_relu = nn.LeakyReLU(0.2)
+        self.leaky_relu = _LeakyReLU(0.2)
         self.fc2 = nn.Linear(1024, 1)
 
     def forward(self, x):

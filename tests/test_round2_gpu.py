@@ -150,7 +150,8 @@ def test_rccl_path_runs_at_world_size_one(pkg, dev):
     for _ in range(2):
         out = S.train_seg_gan.gan_step(inp, tgt, G, D, S.losses.BCEDiceLoss(), nn.BCEWithLogitsLoss(), nn.MSELoss(), og, od, 3)
     # a one-rank all-reduce is the identity and every kernel is deterministic: the two runs agree bit for bit
-    assert [float(v) for v in out] == pytest.approx(got['vals'], rel=0, abs=1e-12)
+    # (IoU / Dice come back as fp64 ratios of the all-reduced sums in the distributed run, as fp32 scalars otherwise)
+    assert [float(v) for v in out] == pytest.approx(got['vals'], rel=0, abs=2e-7)
     assert [float(p.detach().double().abs().sum()) for p in G.parameters()] == got['g']
     assert [float(p.detach().double().abs().sum()) for p in D.parameters()] == got['d']
     assert float(D.conv_blocks[1].conv_block[1].running_var.double().sum()) == got['rm']
