@@ -141,6 +141,23 @@ int64_t ssg_linear_fwd_workspace_bytes(int n, int k, int o);
 int ssg_linear_fwd_f32(const float* x, int n, int k, int ldx, const float* w, int o, const float* bias, int act,
                        float slope, float* y, int ldy, float* ws, int64_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ bf16 pointwise convolution (BASELINE config 4)
+ * SURVEY.md 8(b) `conv2d_{fwd,dgrad,wgrad}_nhwc_bf16` for the 1x1 layers of the EfficientNet MBConv blocks
+ * (efficientnet_pytorch/model.py:40-58: _expand_conv, _project_conv; model.py:172 _conv_head): bf16 operands on
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulation.  bf16 activations are NHWC-with-stride tensors of 16-bit elements whose
+ * channel count and pixel stride are multiples of 8 (16-byte rows).  Weights stay fp32 in the module; per use they are
+ * packed to bf16 rows [rows_pad][Kp] (rows_pad % 128 == 0, Kp % 32 == 0, zero padded): transpose 0 = [O][I] for the
+ * forward, transpose 1 = [I][O] for the input gradient.
+ *   ssg_gemm_bf16        out[p][n] = sum_k x[p][k] * w[n][k] (+ res[p][n]), out/res bf16      (forward and dgrad)
+ *   ssg_gemm_wgrad_bf16  dw[m][n]  = sum_p dy[p][m] * x[p][n], fp32 [M][N] (= OIHW of a 1x1 conv); split-K over pixels
+ *                        with fp32 slabs in `ws` and an ordered reduce (bitwise reproducible) */
+int ssg_pack_weights_bf16(const float* w, int O, int I, int transpose, int rows_pad, int Kp, void* out, void* stream);
+int ssg_gemm_bf16(const void* x, int64_t P, int K, int ldx, const void* w_packed, int Kp, int N,
+                  const void* res, int ldr, void* out, int ldo, void* stream);
+int64_t ssg_gemm_wgrad_bf16_workspace_bytes(int64_t P, int M, int N);
+int ssg_gemm_wgrad_bf16(const void* dy, int ldd, const void* x, int ldx, int64_t P, int M, int N, float* dw,
+                        void* ws, int64_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ layout helpers
  * NCHW (the reference's layout at the boundary: dataset.py:144 tensors, G logits) <->
  * internal NHWC-with-stride.  Pad channels [C, ld) are written as 0. */

@@ -120,6 +120,10 @@ SIGNATURES = {
     'ssg_pixel_gate_bwd_f32': [_P, _I, _P, _I, _P, _I, _L, _I, _P, _I, _P, _I, _P],
     'ssg_linear_fwd_workspace_bytes': [_I, _I, _I],
     'ssg_linear_fwd_f32': [_P, _I, _I, _I, _P, _I, _P, _I, _F, _P, _I, _P, _L, _P],
+    'ssg_pack_weights_bf16': [_P, _I, _I, _I, _I, _I, _P, _P],
+    'ssg_gemm_bf16': [_P, _L, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P],
+    'ssg_gemm_wgrad_bf16_workspace_bytes': [_L, _I, _I],
+    'ssg_gemm_wgrad_bf16': [_P, _I, _P, _I, _L, _I, _I, _P, _P, _L, _P],
     'ssg_tool_mfma_peak_f32': [_P, _I, _I, _P],
     'ssg_tool_copy_f32': [_P, _P, _L, _P],
 }
@@ -131,6 +135,7 @@ _RESTYPES = {
     'ssg_spectral_norm_workspace_bytes': C.c_int64,
     'ssg_linear_fwd_workspace_bytes': C.c_int64,
     'ssg_sample_channel_sum_workspace_bytes': C.c_int64,
+    'ssg_gemm_wgrad_bf16_workspace_bytes': C.c_int64,
 }
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_igemm_mtiles', 'ssg_conv2d_kernel_id', 'ssg_conv2d_wgrad_kernel_id'}
 
