@@ -33,6 +33,7 @@ extern "C" {
 #define SSG_ACT_NONE 0
 #define SSG_ACT_RELU 1
 #define SSG_ACT_LRELU 2
+#define SSG_ACT_SWISH 3   /* x*sigmoid(x) (efficientnet_pytorch/utils.py:37-48); batch-norm apply / backward only */
 
 #define SSG_MAX_TAPS 9
 
@@ -157,6 +158,34 @@ int ssg_gemm_bf16(const void* x, int64_t P, int K, int ldx, const void* w_packed
 int64_t ssg_gemm_wgrad_bf16_workspace_bytes(int64_t P, int M, int N);
 int ssg_gemm_wgrad_bf16(const void* dy, int ldd, const void* x, int ldx, int64_t P, int M, int N, float* dw,
                         void* ws, int64_t ws_bytes, void* stream);
+
+/* bf16 twins of the HBM-bound kernels the MBConv block needs (same arguments and arithmetic as their _f32 namesakes below:
+ * tensors are bf16 in HBM, arithmetic is fp32 in registers, statistics fp64; C % 4 == 0, 8-byte loads per lane).
+ * Batch norm with act = SSG_ACT_SWISH fuses `swish(bn(x))` (model.py:75,80) into the apply pass; its backward recomputes the
+ * pre-activation from x and (scale, shift) (y must be NULL), so the BN output before the swish is never stored. */
+int ssg_bn_stats_bf16(const void* x, int64_t P, int C, int ld, double* sums, int with_count, void* ws, void* stream);
+int ssg_bn_apply_bf16(const void* x, int64_t P, int C, int ld, const float* scale, const float* shift,
+                      const void* res, int ldr, int act, float slope, void* y, int ldy, void* stream);
+int ssg_bn_bwd_reduce_bf16(const void* x, const void* y, const void* dy, int64_t P, int C, int ldx, int ldy, int lddy,
+                           const float* mean, const float* invstd, const float* scale, const float* shift,
+                           int act, float slope, double* sums, int with_count, void* ws, void* stream);
+int ssg_bn_bwd_apply_bf16(const void* x, const void* y, const void* dy, int64_t P, int C, int ldx, int ldy, int lddy,
+                          const float* mean, const float* invstd, const float* weight, const float* scale, const float* shift,
+                          const double* sums, double count, int act, float slope, void* dx, int lddx, void* dres, int lddres,
+                          float* dweight, float* dbias, void* stream);
+int ssg_dwconv2d_fwd_bf16(const void* in, int N, int H, int W, int C, int ld, const float* w, const float* bias, int KH, int KW,
+                          int stride, int pad_top, int pad_left, int OH, int OW, void* out, int ldo, void* stream);
+int ssg_dwconv2d_dgrad_bf16(const void* dout, int lddo, int N, int H, int W, int C, const float* w, int KH, int KW, int stride,
+                            int pad_top, int pad_left, int OH, int OW, void* dx, int lddx, void* stream);
+int ssg_dwconv2d_wgrad_bf16(const void* in, int N, int H, int W, int C, int ld, const void* dout, int lddo, int KH, int KW,
+                            int stride, int pad_top, int pad_left, int OH, int OW, float* dw, void* ws, void* stream);
+int ssg_channel_scale_fwd_bf16(const void* x, int ldx, const float* s, int N, int64_t S, int C, void* y, int ldy, void* stream);
+int ssg_sample_channel_sum_bf16(const void* a, int lda, const void* b, int ldb, int N, int64_t S, int C, float scale,
+                                float* out, void* ws, void* stream);
+int ssg_broadcast_rows_bf16(const float* s, int N, int64_t S, int C, float scale, void* y, int ldy, void* stream);
+int ssg_add_bf16(const void* a, int lda, const void* b, int ldb, int64_t P, int C, void* out, int ldo, void* stream);
+int ssg_convert_f32_to_bf16(const float* src, int ldsrc, int64_t P, int C, void* dst, int lddst, void* stream);
+int ssg_convert_bf16_to_f32(const void* src, int ldsrc, int64_t P, int C, float* dst, int lddst, void* stream);
 
 /* ------------------------------------------------------------------ layout helpers
  * NCHW (the reference's layout at the boundary: dataset.py:144 tensors, G logits) <->

@@ -380,6 +380,29 @@ def gen_unwired(mods):
     print('unwired.npz written,', len(data), 'arrays')
 
 
+def gen_effb4(mods):
+    """BASELINE config 4 at full size: EfficientNet-B4 `extract_features` forward + backward on 4 x 3 x 1024 x 1024 (the
+    reference defines no B4 U-Net: SURVEY.md 0), drop_connect_rate 0 (the RNG-free setting), train mode.  The feature map
+    (4 x 1792 x 32 x 32) and the input gradient are stored as digests plus a strided subset; inputs come from seeds."""
+    import efficientnet_pytorch as ref_e
+    torch.manual_seed(37)
+    net = ref_e.EfficientNet.from_name('efficientnet-b4', override_params=dict(drop_connect_rate=0.0)); net.train()
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(4, 3, 1024, 1024, generator=g)
+    xr = x.clone().requires_grad_(True)
+    f = net.extract_features(xr)
+    dyf = torch.randn(f.shape, generator=torch.Generator().manual_seed(99))
+    f.backward(dyf)
+    feat_params = [(n_, p) for n_, p in net.named_parameters() if not n_.startswith('_fc')]
+    data = dict(shape=np.array(list(x.shape)), seed_model=np.array(37), seed_x=np.array(23), seed_dy=np.array(99),
+                feat_shape=np.array(list(f.shape)), feat_digest=digest(f), feat_sub=f.detach()[:, ::16, ::4, ::4].numpy().copy(),
+                dx_digest=digest(xr.grad), dx_sub=xr.grad[:, :, ::32, ::32].numpy().copy(),
+                gd=np.stack([digest(p.grad) for _, p in feat_params]), names=np.array([n_ for n_, _ in feat_params]),
+                init=np.stack([digest(p) for p in net.parameters()]), bufs=buffer_digests(net))
+    np.savez_compressed(os.path.join(OUT, 'effb4_n4_1024.npz'), **data)
+    print('effb4_n4_1024.npz written; feature digest', data['feat_digest'])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
@@ -401,6 +424,8 @@ def main():
         gen_step(mods, 'step_n2_64', 2, 64, 64, steps=2)
     if a.only in (None, 'step256'):
         gen_step(mods, 'step_n4_256', 4, 256, 256, steps=1, keep_logits=False)
+    if a.only == 'effb4':
+        gen_effb4(mods)                 # ~15 GB RSS, a minute of the reference on 8 cores: on request only
     if a.only == 'step512':
         # BASELINE config 2 at full size (16 x 3 x 512 x 512): ~45 GB RSS and a few minutes of the reference on 8 cores, so
         # it only runs on request (`--only step512`); logits are stored down-sampled 8x (as step256) + digests + scalars.

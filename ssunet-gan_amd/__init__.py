@@ -10,7 +10,7 @@ name the build contract fixes); import it with
 or via the root-level shim `import ssunet_gan_amd`.
 """
 from . import _lib  # noqa: F401
-from . import ops, blocks, archs, normalization, models_seg_gan, losses, metrics, srgan_utils, optim, dp, train_seg_gan, utils  # noqa: F401
+from . import ops, bf16, blocks, archs, normalization, models_seg_gan, losses, metrics, srgan_utils, optim, dp, train_seg_gan, utils  # noqa: F401
 from . import xresidualblock, spectral_norm, batchnorm, efficientnet_pytorch  # noqa: F401  (unwired per-op rows A9-A12)
 from . import train  # noqa: F401  (stage-1 trainer, SURVEY.md 8f N1)
 from . import aerial_image_segmentation_api  # noqa: F401  (sliding-window inference, SURVEY.md 8f N2)

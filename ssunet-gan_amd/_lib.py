@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSG_LIB_PATH: load another build of the library (diagnostic builds of tools/clock_probe.py); default: the in-tree .so
 LIB_PATH = os.environ.get('SSG_LIB_PATH') or os.path.join(_HERE, 'libssunet_hip.so')
 MAX_TAPS = 9
-ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SWISH = 0, 1, 2, 3
 
 
 class HipLibraryError(RuntimeError):
@@ -127,6 +127,13 @@ SIGNATURES = {
     'ssg_tool_mfma_peak_f32': [_P, _I, _I, _P],
     'ssg_tool_copy_f32': [_P, _P, _L, _P],
 }
+
+# bf16 twins: same argument lists as their _f32 namesakes
+for _n in ('ssg_bn_stats', 'ssg_bn_apply', 'ssg_bn_bwd_reduce', 'ssg_bn_bwd_apply', 'ssg_dwconv2d_fwd', 'ssg_dwconv2d_dgrad', 'ssg_dwconv2d_wgrad', 'ssg_channel_scale_fwd', 'ssg_sample_channel_sum', 'ssg_broadcast_rows'):
+    SIGNATURES[_n + '_bf16'] = SIGNATURES[_n + '_f32']
+SIGNATURES['ssg_add_bf16'] = [_P, _I, _P, _I, _L, _I, _P, _I, _P]
+SIGNATURES['ssg_convert_f32_to_bf16'] = [_P, _I, _L, _I, _P, _I, _P]
+SIGNATURES['ssg_convert_bf16_to_f32'] = [_P, _I, _L, _I, _P, _I, _P]
 _RESTYPES = {
     'ssg_conv2d_wgrad_workspace_bytes': C.c_int64,
     'ssg_bn_workspace_bytes': C.c_int64,

@@ -33,9 +33,9 @@ __host__ RedGeom red_geom(long long P, int C) {
 }
 
 // MODE 0: (sum x, sum x^2)      MODE 1: (sum g, sum g*xhat), g = dy * act'(y)      MODE 2: (sum x, -)
-template <int MODE>
+template <int MODE, typename T>
 __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
-    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, long long P, int C,
+    const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, long long P, int C,
     int ldx, int ldy, int lddy, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope,
     int TQ, int PR, long long rows_per_part, double* __restrict__ part /* [parts][2][Cq4] */) {
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
   }
   if (cok) {
     for (long long p = p0 + pr; p < p1; p += PR) {
-      const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
+      const f32x4 xv = ld4(x + p * ldx + 4 * cq);
       if (MODE == 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const double v = (double)xv[e]; s1[e] += v; s2[e] += v * v; }
@@ -68,11 +68,16 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) s1[e] += (double)xv[e];
       } else {
-        f32x4 g = *(const f32x4*)(dy + p * lddy + 4 * cq);
-        if (act != SSG_ACT_NONE) {
+        f32x4 g = ld4(dy + p * lddy + 4 * cq);
+        if (act == SSG_ACT_SWISH) {
+          // smooth activation: its derivative is a function of the pre-activation z = x*scale + shift (recomputed)
+          const f32x4 z = xv * sc + sh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] *= ssg_swish_grad(z[e]);
+        } else if (act != SSG_ACT_NONE) {
           // activation mask: from the saved output, or -- when the forward had no residual -- recomputed with
           // the forward's own expression x*scale + shift (same fp32 fma, same inputs: bitwise the same sign)
-          const f32x4 yv = y ? *(const f32x4*)(y + p * ldy + 4 * cq) : xv * sc + sh;
+          const f32x4 yv = y ? ld4(y + p * ldy + 4 * cq) : xv * sc + sh;
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) g[e] *= (act == SSG_ACT_RELU ? 0.f : slope);
         }
@@ -195,30 +200,32 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   }
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long long P, int C, int ld,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, long long P, int C, int ld,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       const float* __restrict__ res, int ldr, int act, float slope,
-                                                       float* __restrict__ y, int ldy) {
+                                                       const T* __restrict__ res, int ldr, int act, float slope,
+                                                       T* __restrict__ y, int ldy) {
   const int CQ = C / 4;
   const long long total = P * CQ;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long p = i / CQ; const int cq = (int)(i - p * CQ);
-    const f32x4 xv = *(const f32x4*)(x + p * ld + 4 * cq);
+    const f32x4 xv = ld4(x + p * ld + 4 * cq);
     const f32x4 sc = *(const f32x4*)(scale + 4 * cq), sh = *(const f32x4*)(shift + 4 * cq);
     f32x4 v = xv * sc + sh;
-    if (res) v += *(const f32x4*)(res + p * ldr + 4 * cq);
+    if (res) v += ld4(res + p * ldr + 4 * cq);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = ssg_act(v[e], act, slope);
-    *(f32x4*)(y + p * ldy + 4 * cq) = v;
+    st4(y + p * ldy + 4 * cq, v);
   }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, long long P, int C, int ldx,
+    const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, long long P, int C, int ldx,
     int ldy, int lddy, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ weight,
     const float* __restrict__ scale, const float* __restrict__ shift,
-    const double* __restrict__ sums, double count_arg, int act, float slope, float* __restrict__ dx, int lddx,
-    float* __restrict__ dres, int lddres, float* __restrict__ dweight, float* __restrict__ dbias) {
+    const double* __restrict__ sums, double count_arg, int act, float slope, T* __restrict__ dx, int lddx,
+    T* __restrict__ dres, int lddres, float* __restrict__ dweight, float* __restrict__ dbias) {
   const int CQ = C / 4;
   const double count = count_arg > 0 ? count_arg : sums[2 * C];
   const long long total = P * CQ;
@@ -239,15 +246,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   __syncthreads();
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long p = i / CQ; const int cq = (int)(i - p * CQ);
-    f32x4 g = *(const f32x4*)(dy + p * lddy + 4 * cq);
-    const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
-    if (act != SSG_ACT_NONE) {
-      const f32x4 yv = y ? *(const f32x4*)(y + p * ldy + 4 * cq)
+    f32x4 g = ld4(dy + p * lddy + 4 * cq);
+    const f32x4 xv = ld4(x + p * ldx + 4 * cq);
+    if (act == SSG_ACT_SWISH) {
+      const f32x4 z = xv * *(const f32x4*)(scale + 4 * cq) + *(const f32x4*)(shift + 4 * cq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] *= ssg_swish_grad(z[e]);
+    } else if (act != SSG_ACT_NONE) {
+      const f32x4 yv = y ? ld4(y + p * ldy + 4 * cq)
                          : xv * *(const f32x4*)(scale + 4 * cq) + *(const f32x4*)(shift + 4 * cq);
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) g[e] *= (act == SSG_ACT_RELU ? 0.f : slope);
     }
-    if (dres) *(f32x4*)(dres + p * lddres + 4 * cq) = g;
+    if (dres) st4(dres + p * lddres + 4 * cq, g);
     if (dx) {
       f32x4 o;
       // fp64 arithmetic, as ATen's CPU batch-norm backward (accscalar = double for float tensors):
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         const double xh = ((double)xv[e] - k_mean[c]) * k_is[c];
         o[e] = (float)(k_ws[c] * ((double)g[e] - k_m1[c] - xh * k_m2[c]));
       }
-      *(f32x4*)(dx + p * lddx + 4 * cq) = o;
+      st4(dx + p * lddx + 4 * cq, o);
     }
   }
 }
@@ -272,15 +283,15 @@ int elem_grid(long long total) {
   return (int)g;
 }
 
-template <int MODE>
-int run_reduce(const float* x, const float* y, const float* dy, long long P, int C, int ldx, int ldy, int lddy,
+template <int MODE, typename T>
+int run_reduce(const T* x, const T* y, const T* dy, long long P, int C, int ldx, int ldy, int lddy,
                const float* scale, const float* shift,
                const float* mean, const float* invstd, int act, float slope, double* sums, float* fsum, void* ws,
                hipStream_t st, double count_out = 0.0) {
   const RedGeom g = red_geom(P, C);
   const int C4 = 4 * ((C + 3) / 4);
   double* part = (double*)ws;
-  hipLaunchKernelGGL((col_reduce_kernel<MODE>), dim3((unsigned)g.parts, (unsigned)g.groups), dim3(RED_BLOCK), 0, st, x, y, dy,
+  hipLaunchKernelGGL((col_reduce_kernel<MODE, T>), dim3((unsigned)g.parts, (unsigned)g.groups), dim3(RED_BLOCK), 0, st, x, y, dy,
                      P, C, ldx, ldy, lddy, mean, invstd, scale, shift, act, slope, g.TQ, g.PR, g.rows_per_part, part);
   SSG_LAUNCH_CHECK();
   hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C4, sums, fsum, count_out);
@@ -295,17 +306,73 @@ extern "C" int64_t ssg_bn_workspace_bytes(int64_t P, int C) {
   return (int64_t)g.parts * 2 * 4 * ((C + 3) / 4) * (int64_t)sizeof(double);
 }
 
-extern "C" int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, int with_count, void* ws, void* stream) {
+namespace {
+
+template <typename T>
+int bn_stats_impl(const T* x, int64_t P, int C, int ld, double* sums, int with_count, void* ws, void* stream) {
   SSG_REQUIRE(x && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_stats: bad args");
   SSG_REQUIRE(ld % 4 == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN, "bn_stats: alignment");
-  return run_reduce<0>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, sums, nullptr, ws, (hipStream_t)stream,
-                       with_count ? (double)P : 0.0);
+  return run_reduce<0, T>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, sums, nullptr, ws, (hipStream_t)stream,
+                          with_count ? (double)P : 0.0);
+}
+
+template <typename T>
+int bn_apply_impl(const T* x, int64_t P, int C, int ld, const float* scale, const float* shift, const T* res, int ldr, int act, float slope,
+                  T* y, int ldy, void* stream) {
+  SSG_REQUIRE(x && y && scale && shift && P > 0 && C > 0, SSG_EINVAL, "bn_apply: bad args");
+  SSG_REQUIRE(C % 4 == 0 && ld % 4 == 0 && ldy % 4 == 0 && (!res || ldr % 4 == 0), SSG_EALIGN, "bn_apply: C/ld multiples of 4");
+  SSG_REQUIRE(!(act == SSG_ACT_SWISH && res), SSG_EINVAL, "bn_apply: swish with a residual is not supported (its backward needs the pre-activation)");
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, (long long)P, C, ld,
+                     scale, shift, res, ldr, act, slope, y, ldy);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+template <typename T>
+int bn_bwd_reduce_impl(const T* x, const T* y, const T* dy, int64_t P, int C, int ldx, int ldy, int lddy, const float* mean,
+                       const float* invstd, const float* scale, const float* shift, int act, float slope, double* sums, int with_count,
+                       void* ws, void* stream) {
+  SSG_REQUIRE(x && dy && mean && invstd && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_bwd_reduce: bad args");
+  SSG_REQUIRE(act == SSG_ACT_NONE || (y && act != SSG_ACT_SWISH) || (scale && shift), SSG_EINVAL,
+              "bn_bwd_reduce: activation gradient needs y (ReLU family only) or (scale, shift)");
+  SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_reduce: alignment");
+  return run_reduce<1, T>(x, y, dy, P, C, ldx, ldy, lddy, scale, shift, mean, invstd, act, slope, sums, nullptr, ws, (hipStream_t)stream,
+                          with_count ? (double)P : 0.0);
+}
+
+template <typename T>
+int bn_bwd_apply_impl(const T* x, const T* y, const T* dy, int64_t P, int C, int ldx, int ldy, int lddy, const float* mean,
+                      const float* invstd, const float* weight, const float* scale, const float* shift, const double* sums, double count,
+                      int act, float slope, T* dx, int lddx, T* dres, int lddres, float* dweight, float* dbias, void* stream) {
+  SSG_REQUIRE(x && dy && mean && invstd && sums && P > 0 && C > 0, SSG_EINVAL, "bn_bwd_apply: bad args");
+  SSG_REQUIRE(act == SSG_ACT_NONE || (y && act != SSG_ACT_SWISH) || (scale && shift), SSG_EINVAL,
+              "bn_bwd_apply: activation gradient needs y (ReLU family only) or (scale, shift)");
+  SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_apply: alignment");
+  SSG_REQUIRE(C <= 4096, SSG_EINVAL, "bn_bwd_apply: C > 4096");
+  if ((size_t)5 * C * sizeof(double) > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)bn_bwd_apply_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * C * (int)sizeof(double));
+    if (e != hipSuccess) { ssg_set_error("bn_bwd_apply: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), (size_t)5 * C * sizeof(double), (hipStream_t)stream, x, y, dy,
+                     (long long)P, C, ldx, ldy, lddy, mean, invstd, weight, scale, shift, sums, count, act, slope, dx, lddx, dres, lddres,
+                     dweight, dbias);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+}  // namespace
+
+extern "C" int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, int with_count, void* ws, void* stream) {
+  return bn_stats_impl<float>(x, P, C, ld, sums, with_count, ws, stream);
+}
+extern "C" int ssg_bn_stats_bf16(const void* x, int64_t P, int C, int ld, double* sums, int with_count, void* ws, void* stream) {
+  return bn_stats_impl<ssg_bf16>((const ssg_bf16*)x, P, C, ld, sums, with_count, ws, stream);
 }
 
 extern "C" int ssg_channel_sum_f32(const float* x, int64_t P, int C, int ld, float* out, void* ws, void* stream) {
   SSG_REQUIRE(x && out && ws && P > 0 && C > 0, SSG_EINVAL, "channel_sum: bad args");
   SSG_REQUIRE(ld % 4 == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN, "channel_sum: alignment");
-  return run_reduce<2>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, nullptr, out, ws, (hipStream_t)stream);
+  return run_reduce<2, float>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, nullptr, out, ws, (hipStream_t)stream);
 }
 
 extern "C" int ssg_bn_finalize_f32(const double* sums, double count, int C, const float* weight, const float* bias,
@@ -320,22 +387,23 @@ extern "C" int ssg_bn_finalize_f32(const double* sums, double count, int C, cons
 
 extern "C" int ssg_bn_apply_f32(const float* x, int64_t P, int C, int ld, const float* scale, const float* shift,
                                 const float* res, int ldr, int act, float slope, float* y, int ldy, void* stream) {
-  SSG_REQUIRE(x && y && scale && shift && P > 0 && C > 0, SSG_EINVAL, "bn_apply: bad args");
-  SSG_REQUIRE(C % 4 == 0 && ld % 4 == 0 && ldy % 4 == 0 && (!res || ldr % 4 == 0), SSG_EALIGN, "bn_apply: C/ld multiples of 4");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, P, C, ld,
-                     scale, shift, res, ldr, act, slope, y, ldy);
-  SSG_LAUNCH_CHECK();
-  return SSG_OK;
+  return bn_apply_impl<float>(x, P, C, ld, scale, shift, res, ldr, act, slope, y, ldy, stream);
+}
+extern "C" int ssg_bn_apply_bf16(const void* x, int64_t P, int C, int ld, const float* scale, const float* shift,
+                                 const void* res, int ldr, int act, float slope, void* y, int ldy, void* stream) {
+  return bn_apply_impl<ssg_bf16>((const ssg_bf16*)x, P, C, ld, scale, shift, (const ssg_bf16*)res, ldr, act, slope, (ssg_bf16*)y, ldy, stream);
 }
 
 extern "C" int ssg_bn_bwd_reduce_f32(const float* x, const float* y, const float* dy, int64_t P, int C, int ldx, int ldy,
                                      int lddy, const float* mean, const float* invstd, const float* scale, const float* shift,
                                      int act, float slope, double* sums, int with_count, void* ws, void* stream) {
-  SSG_REQUIRE(x && dy && mean && invstd && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_bwd_reduce: bad args");
-  SSG_REQUIRE(act == SSG_ACT_NONE || y || (scale && shift), SSG_EINVAL, "bn_bwd_reduce: activation mask needs y or (scale, shift)");
-  SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_reduce: alignment");
-  return run_reduce<1>(x, y, dy, P, C, ldx, ldy, lddy, scale, shift, mean, invstd, act, slope, sums, nullptr, ws, (hipStream_t)stream,
-                       with_count ? (double)P : 0.0);
+  return bn_bwd_reduce_impl<float>(x, y, dy, P, C, ldx, ldy, lddy, mean, invstd, scale, shift, act, slope, sums, with_count, ws, stream);
+}
+extern "C" int ssg_bn_bwd_reduce_bf16(const void* x, const void* y, const void* dy, int64_t P, int C, int ldx, int ldy,
+                                      int lddy, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                      int act, float slope, double* sums, int with_count, void* ws, void* stream) {
+  return bn_bwd_reduce_impl<ssg_bf16>((const ssg_bf16*)x, (const ssg_bf16*)y, (const ssg_bf16*)dy, P, C, ldx, ldy, lddy, mean, invstd, scale, shift,
+                                      act, slope, sums, with_count, ws, stream);
 }
 
 extern "C" int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float* dy, int64_t P, int C, int ldx, int ldy,
@@ -343,19 +411,16 @@ extern "C" int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float*
                                     const float* scale, const float* shift, const double* sums,
                                     double count, int act, float slope, float* dx, int lddx, float* dres, int lddres,
                                     float* dweight, float* dbias, void* stream) {
-  SSG_REQUIRE(x && dy && mean && invstd && sums && P > 0 && C > 0, SSG_EINVAL, "bn_bwd_apply: bad args");
-  SSG_REQUIRE(act == SSG_ACT_NONE || y || (scale && shift), SSG_EINVAL, "bn_bwd_apply: activation mask needs y or (scale, shift)");
-  SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_apply: alignment");
-  SSG_REQUIRE(C <= 4096, SSG_EINVAL, "bn_bwd_apply: C > 4096");
-  if ((size_t)5 * C * sizeof(double) > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)bn_bwd_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * C * (int)sizeof(double));
-    if (e != hipSuccess) { ssg_set_error("bn_bwd_apply: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-  }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), (size_t)5 * C * sizeof(double), (hipStream_t)stream, x, y, dy,
-                     P, C, ldx, ldy, lddy, mean, invstd, weight, scale, shift, sums, count, act, slope, dx, lddx, dres, lddres,
-                     dweight, dbias);
-  SSG_LAUNCH_CHECK();
-  return SSG_OK;
+  return bn_bwd_apply_impl<float>(x, y, dy, P, C, ldx, ldy, lddy, mean, invstd, weight, scale, shift, sums, count, act, slope, dx, lddx, dres,
+                                  lddres, dweight, dbias, stream);
+}
+extern "C" int ssg_bn_bwd_apply_bf16(const void* x, const void* y, const void* dy, int64_t P, int C, int ldx, int ldy,
+                                     int lddy, const float* mean, const float* invstd, const float* weight,
+                                     const float* scale, const float* shift, const double* sums,
+                                     double count, int act, float slope, void* dx, int lddx, void* dres, int lddres,
+                                     float* dweight, float* dbias, void* stream) {
+  return bn_bwd_apply_impl<ssg_bf16>((const ssg_bf16*)x, (const ssg_bf16*)y, (const ssg_bf16*)dy, P, C, ldx, ldy, lddy, mean, invstd, weight, scale,
+                                     shift, sums, count, act, slope, (ssg_bf16*)dx, lddx, (ssg_bf16*)dres, lddres, dweight, dbias, stream);
 }
 
 extern "C" int ssg_spade_modulate_bwd_sums_f32(const float* x, int ldx, const float* gb, int ldgb, const float* dy, int lddy, int64_t P,

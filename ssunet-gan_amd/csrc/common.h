@@ -9,6 +9,16 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Storage types of the HBM-bound kernels: fp32, or bf16 (BASELINE config 4: bf16 tensors in HBM, fp32 arithmetic in
+// registers, fp64 statistics).  A kernel templated on T reads and writes 4 channels per lane through these two overloads
+// (16 B of fp32 or 8 B of bf16); everything between them is fp32 and identical for both.
+typedef __bf16 ssg_bf16;
+typedef __bf16 ssg_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 ld4(const ssg_bf16* p) { return __builtin_convertvector(*(const ssg_bf16x4*)p, f32x4); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void st4(ssg_bf16* p, f32x4 v) { *(ssg_bf16x4*)p = __builtin_convertvector(v, ssg_bf16x4); }
+
 void ssg_set_error(const char* fmt, ...);
 
 #define SSG_REQUIRE(cond, code, ...)            \
@@ -36,5 +46,12 @@ __device__ __forceinline__ float ssg_act(float v, int act, float slope) {
   // NaN-propagating forms, as ATen's relu (clamp_min) and leaky_relu
   if (act == SSG_ACT_RELU) return v < 0.f ? 0.f : v;
   if (act == SSG_ACT_LRELU) return v > 0.f ? v : v * slope;
+  if (act == SSG_ACT_SWISH) return v / (1.f + expf(-v));                 // x * sigmoid(x) (efficientnet_pytorch/utils.py:37-48)
   return v;
+}
+
+// d act(z) / dz for the activations whose derivative is a function of the pre-activation z
+__device__ __forceinline__ float ssg_swish_grad(float z) {
+  const float s = 1.f / (1.f + expf(-z));
+  return s * (1.f + z * (1.f - s));                                     // utils.py:45-48
 }

@@ -16,12 +16,14 @@ int elem_grid(long long total) {
 #define GRID_STRIDE(i, total) \
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (total); i += (long long)gridDim.x * 256)
 
+template <typename T>
 struct DwArgs {
-  const float* in; const float* w; const float* bias; const float* dout; float* out;
+  const T* in; const float* w; const float* bias; const T* dout; T* out;
   int N, H, W, C, ld, KH, KW, stride, pt, pl, OH, OW, ldo;
 };
 
-__global__ __launch_bounds__(256) void dw_fwd_kernel(const DwArgs a) {
+template <typename T>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const DwArgs<T> a) {
   const int CQ = a.C / 4, KK = a.KH * a.KW;
   const long long total = (long long)a.N * a.OH * a.OW * CQ;
   GRID_STRIDE(i, total) {
@@ -37,17 +39,18 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwArgs a) {
       for (int kx = 0; kx < a.KW; ++kx) {
         const int ix = ox * a.stride + kx - a.pl;
         if ((unsigned)ix >= (unsigned)a.W) continue;
-        const f32x4 v = *(const f32x4*)(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.ld + 4 * cq);
+        const f32x4 v = ld4(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.ld + 4 * cq);
         const int t = ky * a.KW + kx;
         acc[0] += v[0] * wp[t]; acc[1] += v[1] * wp[KK + t]; acc[2] += v[2] * wp[2 * KK + t]; acc[3] += v[3] * wp[3 * KK + t];
       }
     }
-    *(f32x4*)(a.out + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.ldo + 4 * cq) = acc;
+    st4(a.out + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.ldo + 4 * cq, acc);
   }
 }
 
 // dx[n,y,x,c] = sum_{ky,kx} dout[n,(y+pt-ky)/s,(x+pl-kx)/s,c] * w[c,ky,kx]  (where divisible, in range)
-__global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwArgs a) {
+template <typename T>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwArgs<T> a) {
   const int CQ = a.C / 4, KK = a.KH * a.KW;
   const long long total = (long long)a.N * a.H * a.W * CQ;
   GRID_STRIDE(i, total) {
@@ -66,19 +69,20 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwArgs a) {
         if (tx < 0 || tx % a.stride) continue;
         const int ox = tx / a.stride;
         if (ox >= a.OW) continue;
-        const f32x4 g = *(const f32x4*)(a.dout + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.ldo + 4 * cq);
+        const f32x4 g = ld4(a.dout + ((size_t)(n * a.OH + oy) * a.OW + ox) * a.ldo + 4 * cq);
         const int t = ky * a.KW + kx;
         acc[0] += g[0] * wp[t]; acc[1] += g[1] * wp[KK + t]; acc[2] += g[2] * wp[2 * KK + t]; acc[3] += g[3] * wp[3 * KK + t];
       }
     }
-    *(f32x4*)(a.out + ((size_t)(n * a.H + y) * a.W + x) * a.ld + 4 * cq) = acc;
+    st4(a.out + ((size_t)(n * a.H + y) * a.W + x) * a.ld + 4 * cq, acc);
   }
 }
 
 // dw[c, t] = sum_pixels dout[p, c] * in[p*s + t, c]: column reduction per tap.  grid = (parts, channel
 // groups, taps); fp64 block combine; ordered second stage (deterministic).
 constexpr int DW_TQ = 16;                 // channel quads per block row
-__global__ __launch_bounds__(256) void dw_wgrad_partial_kernel(const DwArgs a, long long rows_per_part, double* __restrict__ part) {
+template <typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_partial_kernel(const DwArgs<T> a, long long rows_per_part, double* __restrict__ part) {
   __shared__ double red[256][4];
   const int tid = threadIdx.x, tq = tid % DW_TQ, pr = tid / DW_TQ, PR = 256 / DW_TQ;
   const int CQ = a.C / 4, cq = blockIdx.y * DW_TQ + tq;
@@ -93,8 +97,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial_kernel(const DwArgs a, l
       const int oy = (int)(r % a.OH); const int n = (int)(r / a.OH);
       const int iy = oy * a.stride + ky - a.pt, ix = ox * a.stride + kx - a.pl;
       if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
-        const f32x4 g = *(const f32x4*)(a.dout + (size_t)p * a.ldo + 4 * cq);
-        const f32x4 v = *(const f32x4*)(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.ld + 4 * cq);
+        const f32x4 g = ld4(a.dout + (size_t)p * a.ldo + 4 * cq);
+        const f32x4 v = ld4(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.ld + 4 * cq);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] += (double)g[e] * (double)v[e];
       }
@@ -131,14 +135,15 @@ __global__ void dw_wgrad_final_kernel(const double* __restrict__ part, int parts
 //     [tap][16 quads][4] so one ds_read_b128 serves 4 channels x XT outputs;
 //   * the weight gradient runs one kernel ROW of taps per workgroup (grid.z = KH, not KH*KW): dout is re-read KH
 //     times instead of KH*KW, KW x 4 fp64 accumulators per thread, ordered two-stage reduction as before.
+template <typename T>
 struct DwS1Args {
-  const float* src; const float* w; const float* bias; float* dst;
+  const T* src; const float* w; const float* bias; T* dst;
   int N, SH, SW, DH, DW_, C, lds_, ldd, KH, pt, pl, flip;      // source image SH x SW, destination DH x DW_
 };
 constexpr int DW_XT = 4;
 
-template <int KW>
-__global__ __launch_bounds__(256) void dw_s1_kernel(const DwS1Args a) {
+template <int KW, typename T>
+__global__ __launch_bounds__(256) void dw_s1_kernel(const DwS1Args<T> a) {
   extern __shared__ float w_s[];                         // [KH*KW][16][4]
   const int KK = a.KH * KW;
   const int tid = threadIdx.x, tq = tid & 15, xg = tid >> 4;
@@ -161,12 +166,12 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(const DwS1Args a) {
   for (int ky = 0; ky < a.KH; ++ky) {
     const int iy = oy + ky - a.pt;
     if ((unsigned)iy >= (unsigned)a.SH) continue;
-    const float* row = a.src + ((size_t)(n * a.SH + iy) * a.SW) * a.lds_ + 4 * cq;
+    const T* row = a.src + ((size_t)(n * a.SH + iy) * a.SW) * a.lds_ + 4 * cq;
     f32x4 v[DW_XT + KW - 1];
 #pragma unroll
     for (int j = 0; j < DW_XT + KW - 1; ++j) {
       const int ix = x0 + j - a.pl;
-      v[j] = (unsigned)ix < (unsigned)a.SW ? *(const f32x4*)(row + (size_t)ix * a.lds_) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[j] = (unsigned)ix < (unsigned)a.SW ? ld4(row + (size_t)ix * a.lds_) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float* wrow = w_s + (ky * KW) * 64 + tq * 4;
 #pragma unroll
@@ -176,34 +181,35 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(const DwS1Args a) {
       for (int j = 0; j < DW_XT; ++j) acc[j] += v[j + kx] * wv;
     }
   }
-  float* orow = a.dst + ((size_t)(n * a.DH + oy) * a.DW_) * a.ldd + 4 * cq;
+  T* orow = a.dst + ((size_t)(n * a.DH + oy) * a.DW_) * a.ldd + 4 * cq;
 #pragma unroll
   for (int j = 0; j < DW_XT; ++j)
-    if (x0 + j < a.DW_) *(f32x4*)(orow + (size_t)(x0 + j) * a.ldd) = acc[j];
+    if (x0 + j < a.DW_) st4(orow + (size_t)(x0 + j) * a.ldd, acc[j]);
 }
 
-template <int KW>
-int launch_dw_s1(const DwS1Args& a, hipStream_t st) {
+template <int KW, typename T>
+int launch_dw_s1(const DwS1Args<T>& a, hipStream_t st) {
   const dim3 grid((unsigned)((a.DW_ + 16 * DW_XT - 1) / (16 * DW_XT)), (unsigned)(a.N * a.DH), (unsigned)((a.C / 4 + 15) / 16));
-  hipLaunchKernelGGL(dw_s1_kernel<KW>, grid, dim3(256), (size_t)a.KH * KW * 64 * sizeof(float), st, a);
+  hipLaunchKernelGGL((dw_s1_kernel<KW, T>), grid, dim3(256), (size_t)a.KH * KW * 64 * sizeof(float), st, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
 // returns -1 if the shape is not covered (caller falls back to the generic kernel)
-int dw_s1_dispatch(const DwS1Args& a, int KW, hipStream_t st) {
+template <typename T>
+int dw_s1_dispatch(const DwS1Args<T>& a, int KW, hipStream_t st) {
   if ((long long)a.N * a.DH > 65535 || (a.C / 4 + 15) / 16 > 65535) return -1;     // grid.y / grid.z limits
   switch (KW) {
-    case 3: return launch_dw_s1<3>(a, st);
-    case 5: return launch_dw_s1<5>(a, st);
-    case 7: return launch_dw_s1<7>(a, st);
-    case 9: return launch_dw_s1<9>(a, st);
+    case 3: return launch_dw_s1<3, T>(a, st);
+    case 5: return launch_dw_s1<5, T>(a, st);
+    case 7: return launch_dw_s1<7, T>(a, st);
+    case 9: return launch_dw_s1<9, T>(a, st);
     default: return -1;
   }
 }
 
 // weight gradient, one kernel row ky per blockIdx.z: s[kx][e] += dout[p][c] * in[p + (ky, kx)][c]
-template <int KW>
-__global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs a, long long rows_per_part, double* __restrict__ part) {
+template <int KW, typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs<T> a, long long rows_per_part, double* __restrict__ part) {
   __shared__ double red[256][4];
   const int tid = threadIdx.x, tq = tid % DW_TQ, pr = tid / DW_TQ, PR = 256 / DW_TQ;
   const int CQ = a.C / 4, cq = blockIdx.y * DW_TQ + tq;
@@ -222,13 +228,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs a, long l
       const int oy = (int)(r % a.OH); const int n = (int)(r / a.OH);
       const int iy = oy + ky - a.pt;
       if ((unsigned)iy >= (unsigned)a.H) continue;
-      const f32x4 g = *(const f32x4*)(a.dout + (size_t)p * a.ldo + 4 * cq);
-      const float* row = a.in + ((size_t)(n * a.H + iy) * a.W) * a.ld + 4 * cq;
+      const f32x4 g = ld4(a.dout + (size_t)p * a.ldo + 4 * cq);
+      const T* row = a.in + ((size_t)(n * a.H + iy) * a.W) * a.ld + 4 * cq;
 #pragma unroll
       for (int kx = 0; kx < KW; ++kx) {
         const int ix = ox + kx - a.pl;
         if ((unsigned)ix < (unsigned)a.W) {
-          const f32x4 v = *(const f32x4*)(row + (size_t)ix * a.ld);
+          const f32x4 v = ld4(row + (size_t)ix * a.ld);
 #pragma unroll
           for (int e = 0; e < 4; ++e) s[kx][e] += (double)g[e] * (double)v[e];
         }
@@ -251,9 +257,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs a, long l
     }
   }
 }
-template <int KW>
-void launch_dw_wgrad_s1(const DwArgs& a, long long parts, long long rpp, double* ws, hipStream_t st) {
-  hipLaunchKernelGGL(dw_wgrad_s1_kernel<KW>, dim3((unsigned)parts, (unsigned)((a.C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)a.KH), dim3(256), 0, st, a, rpp, ws);
+template <int KW, typename T>
+void launch_dw_wgrad_s1(const DwArgs<T>& a, long long parts, long long rpp, double* ws, hipStream_t st) {
+  hipLaunchKernelGGL((dw_wgrad_s1_kernel<KW, T>), dim3((unsigned)parts, (unsigned)((a.C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)a.KH), dim3(256), 0, st, a, rpp, ws);
 }
 
 // ---------------------------------------------------------------- unary ops (fwd / bwd)
@@ -314,19 +320,21 @@ __global__ __launch_bounds__(256) void mul_bwd_kernel(const float* __restrict__ 
 }
 
 // y[n,p,c] = x[n,p,c] * s[n,c]  (squeeze-excite gate / drop-connect scale); bwd: dx = g*s, ds = sum_p g*x
-__global__ __launch_bounds__(256) void chscale_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ s, long long S,
-                                                          int N, int C, float* __restrict__ y, int ldy) {
+template <typename T>
+__global__ __launch_bounds__(256) void chscale_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ s, long long S,
+                                                          int N, int C, T* __restrict__ y, int ldy) {
   const int CQ = C / 4;
   GRID_STRIDE(i, (long long)N * S * CQ) {
     const long long p = i / CQ; const int cq = (int)(i - p * CQ);
     const int n = (int)(p / S);
-    *(f32x4*)(y + p * ldy + 4 * cq) = *(const f32x4*)(x + p * ldx + 4 * cq) * *(const f32x4*)(s + (size_t)n * C + 4 * cq);
+    st4(y + p * ldy + 4 * cq, ld4(x + p * ldx + 4 * cq) * *(const f32x4*)(s + (size_t)n * C + 4 * cq));
   }
 }
 // per-sample column reduction: out[n,c] = scale * sum_p a[n,p,c] * (b ? b[n,p,c] : 1).  Two deterministic stages:
 // grid.z slices of the pixel range write fp64 partials [n][slice][C], a finishing kernel adds them in slice order
 // (one slice per (channel block, sample) left 12 workgroups on a 600-MB tensor: 0.74 ms per call in EfficientNet-B4).
-__global__ __launch_bounds__(256) void sample_colsum_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+template <typename T>
+__global__ __launch_bounds__(256) void sample_colsum_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb,
                                                             long long S, int C, long long rows_per_slice, double* __restrict__ part) {
   __shared__ double red[256][4];
   const int tid = threadIdx.x, tq = tid % DW_TQ, pr = tid / DW_TQ, PR = 256 / DW_TQ;
@@ -337,8 +345,8 @@ __global__ __launch_bounds__(256) void sample_colsum_kernel(const float* __restr
   if (cq < CQ)
     for (long long p = p0 + pr; p < p1; p += PR) {
       const size_t row = (size_t)n * S + p;
-      f32x4 v = *(const f32x4*)(a + row * lda + 4 * cq);
-      if (b) v = v * *(const f32x4*)(b + row * ldb + 4 * cq);
+      f32x4 v = ld4(a + row * lda + 4 * cq);
+      if (b) v = v * ld4(b + row * ldb + 4 * cq);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
     }
@@ -372,17 +380,18 @@ int sample_colsum_slices(int N, long long S, int C) {
   if (z < 1) z = 1;
   return (int)z;
 }
+template <typename T>
 __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict__ s, long long S, int N, int C, float scale,
-                                                         float* __restrict__ y, int ldy) {
+                                                         T* __restrict__ y, int ldy) {
   const int CQ = C / 4;
   GRID_STRIDE(i, (long long)N * S * CQ) {
     const long long p = i / CQ; const int cq = (int)(i - p * CQ);
     const int n = (int)(p / S);
-    *(f32x4*)(y + p * ldy + 4 * cq) = scale * *(const f32x4*)(s + (size_t)n * C + 4 * cq);
+    st4(y + p * ldy + 4 * cq, scale * *(const f32x4*)(s + (size_t)n * C + 4 * cq));
   }
 }
 
-int dw_check(const char* what, const float* in, int N, int H, int W, int C, int ld, int KH, int KW, int stride) {
+int dw_check(const char* what, const void* in, int N, int H, int W, int C, int ld, int KH, int KW, int stride) {
   SSG_REQUIRE(in && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C, SSG_EINVAL, "%s: bad tensor", what);
   SSG_REQUIRE(KH >= 1 && KH <= 11 && KW >= 1 && KW <= 11 && stride >= 1 && stride <= 4, SSG_EINVAL, "%s: kernel/stride", what);
   return SSG_OK;
@@ -390,37 +399,87 @@ int dw_check(const char* what, const float* in, int N, int H, int W, int C, int 
 
 }  // namespace
 
-extern "C" int ssg_dwconv2d_fwd_f32(const float* in, int N, int H, int W, int C, int ld, const float* w, const float* bias, int KH, int KW,
-                                    int stride, int pad_top, int pad_left, int OH, int OW, float* out, int ldo, void* stream) {
+namespace {
+
+template <typename T>
+int dwconv_fwd_impl(const T* in, int N, int H, int W, int C, int ld, const float* w, const float* bias, int KH, int KW,
+                    int stride, int pad_top, int pad_left, int OH, int OW, T* out, int ldo, void* stream) {
   int rc = dw_check("dwconv_fwd", in, N, H, W, C, ld, KH, KW, stride);
   if (rc) return rc;
   SSG_REQUIRE(w && out && OH > 0 && OW > 0 && ldo % 4 == 0, SSG_EINVAL, "dwconv_fwd: bad output");
   if (stride == 1 && ssg_aligned16(in) && ssg_aligned16(out)) {
-    const DwS1Args s1{in, w, bias, out, N, H, W, OH, OW, C, ld, ldo, KH, pad_top, pad_left, 0};
-    rc = dw_s1_dispatch(s1, KW, (hipStream_t)stream);
+    const DwS1Args<T> s1{in, w, bias, out, N, H, W, OH, OW, C, ld, ldo, KH, pad_top, pad_left, 0};
+    rc = dw_s1_dispatch<T>(s1, KW, (hipStream_t)stream);
     if (rc >= 0) return rc;
   }
-  DwArgs a{in, w, bias, nullptr, out, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, ldo};
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3(elem_grid((long long)N * OH * OW * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+  DwArgs<T> a{in, w, bias, nullptr, out, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, ldo};
+  hipLaunchKernelGGL(dw_fwd_kernel<T>, dim3(elem_grid((long long)N * OH * OW * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
 
-extern "C" int ssg_dwconv2d_dgrad_f32(const float* dout, int lddo, int N, int H, int W, int C, const float* w, int KH, int KW, int stride,
-                                      int pad_top, int pad_left, int OH, int OW, float* dx, int lddx, void* stream) {
+template <typename T>
+int dwconv_dgrad_impl(const T* dout, int lddo, int N, int H, int W, int C, const float* w, int KH, int KW, int stride,
+                      int pad_top, int pad_left, int OH, int OW, T* dx, int lddx, void* stream) {
   int rc = dw_check("dwconv_dgrad", dout, N, OH, OW, C, lddo, KH, KW, stride);
   if (rc) return rc;
   SSG_REQUIRE(w && dx && H > 0 && W > 0 && lddx % 4 == 0, SSG_EINVAL, "dwconv_dgrad: bad output");
   if (stride == 1 && ssg_aligned16(dout) && ssg_aligned16(dx)) {
     // dx = correlation of dout with the flipped kernel, pads K-1-pad
-    const DwS1Args s1{dout, w, nullptr, dx, N, OH, OW, H, W, C, lddo, lddx, KH, KH - 1 - pad_top, KW - 1 - pad_left, 1};
-    rc = dw_s1_dispatch(s1, KW, (hipStream_t)stream);
+    const DwS1Args<T> s1{dout, w, nullptr, dx, N, OH, OW, H, W, C, lddo, lddx, KH, KH - 1 - pad_top, KW - 1 - pad_left, 1};
+    rc = dw_s1_dispatch<T>(s1, KW, (hipStream_t)stream);
     if (rc >= 0) return rc;
   }
-  DwArgs a{nullptr, w, nullptr, dout, dx, N, H, W, C, lddx, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
-  hipLaunchKernelGGL(dw_dgrad_kernel, dim3(elem_grid((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+  DwArgs<T> a{nullptr, w, nullptr, dout, dx, N, H, W, C, lddx, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
+  hipLaunchKernelGGL(dw_dgrad_kernel<T>, dim3(elem_grid((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
+}
+
+template <typename T>
+int dwconv_wgrad_impl(const T* in, int N, int H, int W, int C, int ld, const T* dout, int lddo, int KH, int KW,
+                      int stride, int pad_top, int pad_left, int OH, int OW, float* dw, void* ws, void* stream) {
+  int rc = dw_check("dwconv_wgrad", in, N, H, W, C, ld, KH, KW, stride);
+  if (rc) return rc;
+  SSG_REQUIRE(dout && dw && ws && OH > 0 && OW > 0, SSG_EINVAL, "dwconv_wgrad: bad args");
+  const long long P = (long long)N * OH * OW;
+  long long parts = (P + 255) / 256; if (parts > 256) parts = 256; if (parts < 1) parts = 1;
+  const long long rpp = (P + parts - 1) / parts;
+  parts = (P + rpp - 1) / rpp;
+  DwArgs<T> a{in, nullptr, nullptr, dout, nullptr, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1 && (KW == 3 || KW == 5 || KW == 7 || KW == 9)) {
+    if (KW == 3) launch_dw_wgrad_s1<3, T>(a, parts, rpp, (double*)ws, st);
+    else if (KW == 5) launch_dw_wgrad_s1<5, T>(a, parts, rpp, (double*)ws, st);
+    else if (KW == 7) launch_dw_wgrad_s1<7, T>(a, parts, rpp, (double*)ws, st);
+    else launch_dw_wgrad_s1<9, T>(a, parts, rpp, (double*)ws, st);
+  } else
+  hipLaunchKernelGGL(dw_wgrad_partial_kernel<T>, dim3((unsigned)parts, (unsigned)((C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)(KH * KW)), dim3(256), 0, st,
+                     a, rpp, (double*)ws);
+  SSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dw_wgrad_final_kernel, dim3((unsigned)((KH * KW * C + 127) / 128)), dim3(128), 0, st, (const double*)ws, (int)parts, KH * KW, C, dw);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+}  // namespace
+
+extern "C" int ssg_dwconv2d_fwd_f32(const float* in, int N, int H, int W, int C, int ld, const float* w, const float* bias, int KH, int KW,
+                                    int stride, int pad_top, int pad_left, int OH, int OW, float* out, int ldo, void* stream) {
+  return dwconv_fwd_impl<float>(in, N, H, W, C, ld, w, bias, KH, KW, stride, pad_top, pad_left, OH, OW, out, ldo, stream);
+}
+extern "C" int ssg_dwconv2d_fwd_bf16(const void* in, int N, int H, int W, int C, int ld, const float* w, const float* bias, int KH, int KW,
+                                     int stride, int pad_top, int pad_left, int OH, int OW, void* out, int ldo, void* stream) {
+  return dwconv_fwd_impl<ssg_bf16>((const ssg_bf16*)in, N, H, W, C, ld, w, bias, KH, KW, stride, pad_top, pad_left, OH, OW, (ssg_bf16*)out, ldo, stream);
+}
+
+extern "C" int ssg_dwconv2d_dgrad_f32(const float* dout, int lddo, int N, int H, int W, int C, const float* w, int KH, int KW, int stride,
+                                      int pad_top, int pad_left, int OH, int OW, float* dx, int lddx, void* stream) {
+  return dwconv_dgrad_impl<float>(dout, lddo, N, H, W, C, w, KH, KW, stride, pad_top, pad_left, OH, OW, dx, lddx, stream);
+}
+extern "C" int ssg_dwconv2d_dgrad_bf16(const void* dout, int lddo, int N, int H, int W, int C, const float* w, int KH, int KW, int stride,
+                                       int pad_top, int pad_left, int OH, int OW, void* dx, int lddx, void* stream) {
+  return dwconv_dgrad_impl<ssg_bf16>((const ssg_bf16*)dout, lddo, N, H, W, C, w, KH, KW, stride, pad_top, pad_left, OH, OW, (ssg_bf16*)dx, lddx, stream);
 }
 
 extern "C" int64_t ssg_dwconv2d_wgrad_workspace_bytes(int N, int OH, int OW, int C, int KH, int KW) {
@@ -431,27 +490,12 @@ extern "C" int64_t ssg_dwconv2d_wgrad_workspace_bytes(int N, int OH, int OW, int
 
 extern "C" int ssg_dwconv2d_wgrad_f32(const float* in, int N, int H, int W, int C, int ld, const float* dout, int lddo, int KH, int KW,
                                       int stride, int pad_top, int pad_left, int OH, int OW, float* dw, void* ws, void* stream) {
-  int rc = dw_check("dwconv_wgrad", in, N, H, W, C, ld, KH, KW, stride);
-  if (rc) return rc;
-  SSG_REQUIRE(dout && dw && ws && OH > 0 && OW > 0, SSG_EINVAL, "dwconv_wgrad: bad args");
-  const long long P = (long long)N * OH * OW;
-  long long parts = (P + 255) / 256; if (parts > 256) parts = 256; if (parts < 1) parts = 1;
-  const long long rpp = (P + parts - 1) / parts;
-  parts = (P + rpp - 1) / rpp;
-  DwArgs a{in, nullptr, nullptr, dout, nullptr, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
-  hipStream_t st = (hipStream_t)stream;
-  if (stride == 1 && (KW == 3 || KW == 5 || KW == 7 || KW == 9)) {
-    if (KW == 3) launch_dw_wgrad_s1<3>(a, parts, rpp, (double*)ws, st);
-    else if (KW == 5) launch_dw_wgrad_s1<5>(a, parts, rpp, (double*)ws, st);
-    else if (KW == 7) launch_dw_wgrad_s1<7>(a, parts, rpp, (double*)ws, st);
-    else launch_dw_wgrad_s1<9>(a, parts, rpp, (double*)ws, st);
-  } else
-  hipLaunchKernelGGL(dw_wgrad_partial_kernel, dim3((unsigned)parts, (unsigned)((C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)(KH * KW)), dim3(256), 0, st,
-                     a, rpp, (double*)ws);
-  SSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dw_wgrad_final_kernel, dim3((unsigned)((KH * KW * C + 127) / 128)), dim3(128), 0, st, (const double*)ws, (int)parts, KH * KW, C, dw);
-  SSG_LAUNCH_CHECK();
-  return SSG_OK;
+  return dwconv_wgrad_impl<float>(in, N, H, W, C, ld, dout, lddo, KH, KW, stride, pad_top, pad_left, OH, OW, dw, ws, stream);
+}
+extern "C" int ssg_dwconv2d_wgrad_bf16(const void* in, int N, int H, int W, int C, int ld, const void* dout, int lddo, int KH, int KW,
+                                       int stride, int pad_top, int pad_left, int OH, int OW, float* dw, void* ws, void* stream) {
+  return dwconv_wgrad_impl<ssg_bf16>((const ssg_bf16*)in, N, H, W, C, ld, (const ssg_bf16*)dout, lddo, KH, KW, stride, pad_top, pad_left, OH, OW, dw, ws,
+                                     stream);
 }
 
 extern "C" int ssg_unary_fwd_f32(const float* x, int ldx, int64_t P, int C, int op, float* y, int ldy, void* stream) {
@@ -479,21 +523,20 @@ extern "C" int ssg_mul_bwd_f32(const float* a, int lda, const float* b, int ldb,
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
-extern "C" int ssg_channel_scale_fwd_f32(const float* x, int ldx, const float* s, int N, int64_t S, int C, float* y, int ldy, void* stream) {
+namespace {
+template <typename T>
+int channel_scale_impl(const T* x, int ldx, const float* s, int N, int64_t S, int C, T* y, int ldy, void* stream) {
   SSG_REQUIRE(x && s && y && N > 0 && S > 0 && C > 0 && C % 4 == 0, SSG_EINVAL, "channel_scale: bad args");
-  hipLaunchKernelGGL(chscale_fwd_kernel, dim3(elem_grid((long long)N * S * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, s, (long long)S, N, C, y, ldy);
+  hipLaunchKernelGGL(chscale_fwd_kernel<T>, dim3(elem_grid((long long)N * S * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, s, (long long)S, N, C, y, ldy);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
-extern "C" int64_t ssg_sample_channel_sum_workspace_bytes(int N, int64_t S, int C) {
-  return (int64_t)N * sample_colsum_slices(N, S, C) * C * (int64_t)sizeof(double);
-}
-extern "C" int ssg_sample_channel_sum_f32(const float* a, int lda, const float* b, int ldb, int N, int64_t S, int C, float scale, float* out,
-                                          void* ws, void* stream) {
+template <typename T>
+int sample_channel_sum_impl(const T* a, int lda, const T* b, int ldb, int N, int64_t S, int C, float scale, float* out, void* ws, void* stream) {
   SSG_REQUIRE(a && out && ws && N > 0 && S > 0 && C > 0 && C % 4 == 0, SSG_EINVAL, "sample_channel_sum: bad args");
   const int z = sample_colsum_slices(N, S, C);
   const long long rps = (S + z - 1) / z;
-  hipLaunchKernelGGL(sample_colsum_kernel, dim3((unsigned)((C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)N, (unsigned)z), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(sample_colsum_kernel<T>, dim3((unsigned)((C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)N, (unsigned)z), dim3(256), 0, (hipStream_t)stream,
                      a, lda, b, ldb, (long long)S, C, rps, (double*)ws);
   SSG_LAUNCH_CHECK();
   hipLaunchKernelGGL(sample_colsum_final_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const double*)ws, z, N * C, C,
@@ -501,9 +544,35 @@ extern "C" int ssg_sample_channel_sum_f32(const float* a, int lda, const float* 
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
-extern "C" int ssg_broadcast_rows_f32(const float* s, int N, int64_t S, int C, float scale, float* y, int ldy, void* stream) {
+template <typename T>
+int broadcast_rows_impl(const float* s, int N, int64_t S, int C, float scale, T* y, int ldy, void* stream) {
   SSG_REQUIRE(s && y && N > 0 && S > 0 && C > 0 && C % 4 == 0, SSG_EINVAL, "broadcast_rows: bad args");
-  hipLaunchKernelGGL(bcast_rows_kernel, dim3(elem_grid((long long)N * S * (C / 4))), dim3(256), 0, (hipStream_t)stream, s, (long long)S, N, C, scale, y, ldy);
+  hipLaunchKernelGGL(bcast_rows_kernel<T>, dim3(elem_grid((long long)N * S * (C / 4))), dim3(256), 0, (hipStream_t)stream, s, (long long)S, N, C, scale, y, ldy);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
+}
+}  // namespace
+
+extern "C" int ssg_channel_scale_fwd_f32(const float* x, int ldx, const float* s, int N, int64_t S, int C, float* y, int ldy, void* stream) {
+  return channel_scale_impl<float>(x, ldx, s, N, S, C, y, ldy, stream);
+}
+extern "C" int ssg_channel_scale_fwd_bf16(const void* x, int ldx, const float* s, int N, int64_t S, int C, void* y, int ldy, void* stream) {
+  return channel_scale_impl<ssg_bf16>((const ssg_bf16*)x, ldx, s, N, S, C, (ssg_bf16*)y, ldy, stream);
+}
+extern "C" int64_t ssg_sample_channel_sum_workspace_bytes(int N, int64_t S, int C) {
+  return (int64_t)N * sample_colsum_slices(N, S, C) * C * (int64_t)sizeof(double);
+}
+extern "C" int ssg_sample_channel_sum_f32(const float* a, int lda, const float* b, int ldb, int N, int64_t S, int C, float scale, float* out,
+                                          void* ws, void* stream) {
+  return sample_channel_sum_impl<float>(a, lda, b, ldb, N, S, C, scale, out, ws, stream);
+}
+extern "C" int ssg_sample_channel_sum_bf16(const void* a, int lda, const void* b, int ldb, int N, int64_t S, int C, float scale, float* out,
+                                           void* ws, void* stream) {
+  return sample_channel_sum_impl<ssg_bf16>((const ssg_bf16*)a, lda, (const ssg_bf16*)b, ldb, N, S, C, scale, out, ws, stream);
+}
+extern "C" int ssg_broadcast_rows_f32(const float* s, int N, int64_t S, int C, float scale, float* y, int ldy, void* stream) {
+  return broadcast_rows_impl<float>(s, N, S, C, scale, y, ldy, stream);
+}
+extern "C" int ssg_broadcast_rows_bf16(const float* s, int N, int64_t S, int C, float scale, void* y, int ldy, void* stream) {
+  return broadcast_rows_impl<ssg_bf16>(s, N, S, C, scale, (ssg_bf16*)y, ldy, stream);
 }

@@ -133,6 +133,19 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restr
   }
 }
 
+// dst[p][c] = (TD) (a[p][c] (+ b[p][c])): dtype conversion between the fp32 and bf16 tensor families, and the bf16 residual add
+template <typename TA, typename TD>
+__global__ __launch_bounds__(256) void rows_convert_add_kernel(const TA* __restrict__ a, int lda, const TA* __restrict__ b, int ldb, long long P, int C,
+                                                               TD* __restrict__ dst, int ldd) {
+  const int CQ = C / 4;
+  GRID_STRIDE(i, P * CQ) {
+    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
+    f32x4 v = ld4(a + p * lda + 4 * cq);
+    if (b) v += ld4(b + p * ldb + 4 * cq);
+    st4(dst + p * ldd + 4 * cq, v);
+  }
+}
+
 __global__ __launch_bounds__(256) void clamp_multi_kernel(const void* const* __restrict__ ptrs, const long long* __restrict__ sizes,
                                                           const int* __restrict__ blk_tensor, const int* __restrict__ blk_chunk, int stride,
                                                           float lo, float hi) {
@@ -270,6 +283,29 @@ extern "C" int ssg_pixel_gate_bwd_f32(const float* x, int ldx, const float* g, i
   SSG_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddg % 4 == 0 && ssg_aligned16(dg), SSG_EALIGN, "pixel_gate_bwd: strides");
   hipLaunchKernelGGL(pixel_gate_bwd_kernel, dim3(elem_grid(P * 16)), dim3(256), 0, (hipStream_t)stream, x, ldx, g, ldg, dy, lddy, (long long)P, C,
                      dx, lddx, dg, lddg);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+/* dtype conversion between the fp32 and the bf16 tensor family (rows of C channels, C % 4 == 0), and the bf16 residual add */
+extern "C" int ssg_convert_f32_to_bf16(const float* src, int ldsrc, int64_t P, int C, void* dst, int lddst, void* stream) {
+  SSG_REQUIRE(src && dst && P > 0 && C > 0 && C % 4 == 0 && ldsrc % 4 == 0 && lddst % 4 == 0, SSG_EINVAL, "convert_f32_to_bf16: bad args");
+  hipLaunchKernelGGL((rows_convert_add_kernel<float, ssg_bf16>), dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, ldsrc,
+                     (const float*)nullptr, 0, (long long)P, C, (ssg_bf16*)dst, lddst);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_convert_bf16_to_f32(const void* src, int ldsrc, int64_t P, int C, float* dst, int lddst, void* stream) {
+  SSG_REQUIRE(src && dst && P > 0 && C > 0 && C % 4 == 0 && ldsrc % 4 == 0 && lddst % 4 == 0, SSG_EINVAL, "convert_bf16_to_f32: bad args");
+  hipLaunchKernelGGL((rows_convert_add_kernel<ssg_bf16, float>), dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const ssg_bf16*)src,
+                     ldsrc, (const ssg_bf16*)nullptr, 0, (long long)P, C, dst, lddst);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_add_bf16(const void* a, int lda, const void* b, int ldb, int64_t P, int C, void* out, int ldo, void* stream) {
+  SSG_REQUIRE(a && b && out && P > 0 && C > 0 && C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0, SSG_EINVAL, "add_bf16: bad args");
+  hipLaunchKernelGGL((rows_convert_add_kernel<ssg_bf16, ssg_bf16>), dim3(elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const ssg_bf16*)a,
+                     lda, (const ssg_bf16*)b, ldb, (long long)P, C, (ssg_bf16*)out, ldo);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -3,7 +3,8 @@ efficientnet_pytorch/model.py:18-99,132-218 of the reference; parameter names an
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import bf16, ops
+from .._lib import ACT_SWISH
 from .utils import (MemoryEfficientSwish, Swish, drop_connect, get_model_params, get_same_padding_conv2d, round_filters,
                     round_repeats)
 
@@ -37,11 +38,15 @@ class MBConvBlock(nn.Module):
         self._swish = MemoryEfficientSwish()
 
     def forward(self, inputs, drop_connect_rate=None):
+        if torch.is_tensor(inputs) and inputs.dtype == torch.bfloat16:
+            return self._forward_bf16(inputs, drop_connect_rate)
         x = ops.as_nhwc(inputs)
         inputs = x
+        # swish(bn(.)) (model.py:75,80) is ONE pass: the batch-norm apply kernel evaluates the swish, and the backward
+        # recomputes the pre-activation from the conv output and (scale, shift) instead of storing it
         if self._block_args.expand_ratio != 1:
-            x = self._swish(ops.batch_norm_act(self._expand_conv(x), self._bn0))
-        x = self._swish(ops.batch_norm_act(self._depthwise_conv(x), self._bn1))
+            x = ops.batch_norm_act(self._expand_conv(x), self._bn0, act=ACT_SWISH)
+        x = ops.batch_norm_act(self._depthwise_conv(x), self._bn1, act=ACT_SWISH)
         if self.has_se:
             sq = ops.global_avgpool(x)
             sq = self._se_expand(self._swish(self._se_reduce(sq)))
@@ -57,6 +62,32 @@ class MBConvBlock(nn.Module):
         if skip:
             x = drop_connect(x, p=drop_connect_rate, training=self.training)
             x = ops.add(x, inputs)
+        return x
+
+    def _forward_bf16(self, inputs, drop_connect_rate=None):
+        """The same block on a bf16 tensor (BASELINE config 4): pointwise convs on the bf16 MFMA GEMM, depthwise / batch norm
+        / squeeze-excite pooling and gating on the bf16 instantiations; the two tiny SE convs see fp32 [N, C, 1, 1]."""
+        x = inputs
+        dw = self._depthwise_conv
+        if self._block_args.expand_ratio != 1:
+            x = bf16.batch_norm_act(bf16.conv1x1(x, self._expand_conv.weight), self._bn0, act=ACT_SWISH)
+        x = bf16.batch_norm_act(bf16.dwconv2d(x, dw.weight, dw.stride[0], dw.static_pad), self._bn1, act=ACT_SWISH)
+        if self.has_se:
+            sq = bf16.global_avgpool(x)
+            sq = self._se_expand(self._swish(self._se_reduce(sq)))
+            x = bf16.channel_scale(x, ops.sigmoid(sq))
+        x = bf16.conv1x1(x, self._project_conv.weight)
+        a = self._block_args
+        skip = self.id_skip and a.stride == 1 and a.input_filters == a.output_filters
+        if skip and not (drop_connect_rate and self.training):
+            return bf16.batch_norm_act(x, self._bn2, res=inputs)
+        x = bf16.batch_norm_act(x, self._bn2)
+        if skip:
+            n, c = x.shape[0], x.shape[1]
+            keep = 1 - drop_connect_rate                                     # utils.py:83-92
+            mask = torch.floor(keep + torch.rand([n, 1, 1, 1], dtype=torch.float32, device=x.device)) / keep
+            x = bf16.channel_scale(x, mask.expand(n, c, 1, 1).contiguous(memory_format=torch.channels_last))
+            x = bf16.add(x, inputs)
         return x
 
     def set_swish(self, memory_efficient=True):
@@ -102,14 +133,30 @@ class EfficientNet(nn.Module):
         for b in self._blocks:
             b.set_swish(memory_efficient)
 
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (default: the reference's arithmetic) or torch.bfloat16 (BASELINE config 4): activations between
+        the stem and the head live in HBM as bf16, the 1x1 convolutions run on v_mfma_f32_32x32x16_bf16 with fp32
+        accumulation; parameters, batch-norm statistics, SE gates and every gradient of a parameter stay fp32.  The stem
+        (a 3-channel 3x3 stride-2 conv) stays on the fp32 path; extract_features still takes and returns fp32 tensors."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError('compute dtype must be torch.float32 or torch.bfloat16')
+        self._ssg_dtype = dtype
+        return self
+
     def extract_features(self, inputs):
-        x = self._swish(ops.batch_norm_act(self._conv_stem(ops.as_nhwc(inputs)), self._bn0))
+        x = ops.batch_norm_act(self._conv_stem(ops.as_nhwc(inputs)), self._bn0, act=ACT_SWISH)
+        lowp = getattr(self, '_ssg_dtype', torch.float32) == torch.bfloat16
+        if lowp:
+            x = bf16.to_bf16(x)
         for idx, block in enumerate(self._blocks):
             rate = self._global_params.drop_connect_rate
             if rate:
                 rate *= float(idx) / len(self._blocks)
             x = block(x, drop_connect_rate=rate)
-        return self._swish(ops.batch_norm_act(self._conv_head(x), self._bn1))
+        if lowp:
+            x = bf16.batch_norm_act(bf16.conv1x1(x, self._conv_head.weight), self._bn1, act=ACT_SWISH)
+            return bf16.to_f32(x)
+        return ops.batch_norm_act(self._conv_head(x), self._bn1, act=ACT_SWISH)
 
     def forward(self, inputs):
         raise NotImplementedError('the ImageNet classifier head is out of scope (SURVEY.md 2, row 10); use extract_features')

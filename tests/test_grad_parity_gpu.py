@@ -28,6 +28,7 @@ pytestmark = pytest.mark.gpu
 ACT_NEAR_TIE = 2e-4          # |pre-activation| where a mask may legitimately differ (activations are O(1) after batch norm)
 POOL_NEAR_TIE = 1e-3         # top-2 gap of a 2x2 window where the argmax may legitimately differ
 GRAD_RTOL = 2e-4             # HIP fp32 gradient vs fp64 on the same piece, relative to the tensor's max |g|
+GRAD_ATOL = 1e-7             # absolute floor (sums of ~1e4 terms of magnitude ~1e-4 that cancel exactly in exact arithmetic)
 LR = 2e-5
 
 
@@ -167,14 +168,15 @@ def test_step_gradients_vs_fp64_on_the_same_activation_pattern(pkg, dev):
         b = b.clamp(-0.8, 0.8)
         scale = b.abs().max().item()
         err = (a.double() - b).abs().max().item()
-        rel.append(err / (scale + 1e-12) if scale > 1e-9 else 0.0)
-        assert err <= GRAD_RTOL * scale + 1e-9, '%s: |g_hip - g_fp64| = %.3e at max|g| = %.3e' % (name, err, scale)
+        rel.append(err / scale if scale > 1e-6 else 0.0)
+        # (a conv bias in front of a batch norm has a true gradient of exactly 0: only the absolute floor applies there)
+        assert err <= GRAD_RTOL * scale + GRAD_ATOL, '%s: |g_hip - g_fp64| = %.3e at max|g| = %.3e' % (name, err, scale)
     rel = np.array(rel)
     print('gradient error vs fp64 on the same piece: median %.2e  p95 %.2e  max %.2e' % (np.median(rel), np.quantile(rel, 0.95), rel.max()))
     # the same measure for the reference's fp32 CPU path against fp64 on ITS piece: HIP must be in the same class
     g64_ref, _ = _oracle_run(O, inp, tgt, O.ActivationPattern('impose', [
         (r[1] > 0) if r[0] == 'act' else (((r[2] // r[1].shape[3]) % 2) * 2 + (r[2] % r[1].shape[3]) % 2) for r in rec.items]), torch.float64)
-    rel_ref = np.array([(a.double() - b).abs().max().item() / (b.abs().max().item() + 1e-12) if b.abs().max().item() > 1e-9 else 0.0
+    rel_ref = np.array([(a.double() - b).abs().max().item() / b.abs().max().item() if b.abs().max().item() > 1e-6 else 0.0
                         for a, b in zip(g_ref32, g64_ref)])
     print('reference fp32 CPU path, same measure:            median %.2e  p95 %.2e  max %.2e' % (np.median(rel_ref), np.quantile(rel_ref, 0.95), rel_ref.max()))
     assert np.median(rel) <= 4 * np.median(rel_ref) + 1e-7
@@ -183,7 +185,7 @@ def test_step_gradients_vs_fp64_on_the_same_activation_pattern(pkg, dev):
     wrong = 0; clear = 0
     for name, a0, a1, b in zip(names, p0, p1, g64):
         b = b.clamp(-0.8, 0.8)
-        thr = 4 * GRAD_RTOL * b.abs().max().item() + 1e-9
+        thr = 4 * (GRAD_RTOL * b.abs().max().item() + GRAD_ATOL)
         m = b.abs() > thr
         step = (a1.double() - a0.double())
         assert step.abs().max().item() <= LR * 1.0001 + 1e-7 * a0.abs().max().item(), '%s moved by more than lr' % name
