@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 
 ACT_NEAR_TIE = 2e-4          # |pre-activation| where a mask may legitimately differ (activations are O(1) after batch norm)
 POOL_NEAR_TIE = 1e-3         # top-2 gap of a 2x2 window where the argmax may legitimately differ
-GRAD_RTOL = 2e-4             # HIP fp32 gradient vs fp64 on the same piece, relative to the tensor's max |g|
+GRAD_RTOL = 1e-4             # HIP fp32 gradient vs fp64 on the same piece, relative to the tensor's max |g|
 GRAD_ATOL = 1e-7             # absolute floor (sums of ~1e4 terms of magnitude ~1e-4 that cancel exactly in exact arithmetic)
 LR = 2e-5
 

@@ -56,10 +56,11 @@ def main():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--only', choices=['both', 'bf16'], default='both', help="'bf16': skip the fp32 leg (for a clean kernel trace)")
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     flop_img = 3 * 2 * GMAC_FWD_B4_1024 * 1e9 * (args.size / 1024.0) ** 2
-    dt32, _ = run(torch.float32, args, dev, False)
+    dt32 = run(torch.float32, args, dev, False)[0] if args.only == 'both' else float('nan')
     dt16, prof = run(torch.bfloat16, args, dev, True)
     agg = {}
     for label, flops, nbytes, e0, e1 in prof or []:
@@ -71,7 +72,8 @@ def main():
     line = {
         'metric': 'EfficientNet-B4 extract_features fwd+bwd images/sec (1024^2 tiles)', 'unit': 'images/sec', 'n_gpus': 1,
         'value': round(args.batch / dt16, 2), 'dtype': 'bf16', 'ms_per_step': round(dt16 * 1e3, 2),
-        'fp32_value': round(args.batch / dt32, 2), 'fp32_ms_per_step': round(dt32 * 1e3, 2), 'bf16_speedup': round(dt32 / dt16, 3),
+        'fp32_value': round(args.batch / dt32, 2) if dt32 == dt32 else None, 'fp32_ms_per_step': round(dt32 * 1e3, 2) if dt32 == dt32 else None,
+        'bf16_speedup': round(dt32 / dt16, 3) if dt32 == dt32 else None,
         'steps': args.steps, 'warmup': args.warmup, 'data': 'synthetic',
         'config': {'workload': 'EfficientNet-B4 encoder (efficientnet_pytorch/model.py:202-218), train mode, default drop_connect_rate 0.2, '
                                '%d x 3x%dx%d per GPU' % (args.batch, args.size, args.size)},
