@@ -143,6 +143,31 @@ def gen_step(mods, name, n, h, w, steps, keep_logits=True):
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **data)
 
 
+def gen_step_sn(mods):
+    """BASELINE config 5, "spectral-norm discriminator on": the reference's own scripts/spectral_norm.py (vendored torch
+    spectral_norm; imported by nobody in the reference -- SURVEY.md 0) applied to the eight discriminator convs, then one
+    G+D step of train_seg_gan.py:182-233 on 2 x 3 x 64 x 64 (two steps: u/v carry over)."""
+    import spectral_norm as ref_sn
+    G, D, _, _ = ref_models(mods)
+    convs = [m for m in D.modules() if isinstance(m, nn.Conv2d)]
+    assert len(convs) == 8
+    for m in convs:                                   # consumes the RNG for u, v right after the model init (seed 41)
+        ref_sn.spectral_norm(m)
+    og = torch.optim.Adam(params=filter(lambda p: p.requires_grad, G.parameters()), lr=2e-5)
+    od = torch.optim.Adam(params=filter(lambda p: p.requires_grad, D.parameters()), lr=2e-5)
+    inp, tgt = synthetic_batch(2, 64, 64)
+    data = dict(seed_model=np.array(41), seed_batch=np.array(7), shape=np.array([2, 3, 64, 64]),
+                state_keys_D=np.array(list(D.state_dict().keys())), param_names_D=np.array([k for k, _ in D.named_parameters()]),
+                init_D=param_digests(D), init_uv=buffer_digests(D))
+    for s in range(2):
+        rec = {}
+        ref_step(mods, G, D, og, od, inp, tgt, rec)
+        for k, v in rec.items():
+            data['s%d_%s' % (s, k)] = v
+        print('step_sn', s, rec['scalars'])
+    np.savez_compressed(os.path.join(OUT, 'step_sn_n2_64.npz'), **data)
+
+
 def _grad_pack(mod, x, extra_inputs=()):
     x = x.clone().requires_grad_(True)
     y = mod(x, *extra_inputs) if extra_inputs else mod(x)
@@ -424,6 +449,8 @@ def main():
         gen_step(mods, 'step_n2_64', 2, 64, 64, steps=2)
     if a.only in (None, 'step256'):
         gen_step(mods, 'step_n4_256', 4, 256, 256, steps=1, keep_logits=False)
+    if a.only in (None, 'stepsn'):
+        gen_step_sn(mods)
     if a.only == 'effb4':
         gen_effb4(mods)                 # ~15 GB RSS, a minute of the reference on 8 cores: on request only
     if a.only == 'step512':

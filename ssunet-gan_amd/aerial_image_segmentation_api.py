@@ -1,19 +1,32 @@
 """Sliding-window full-image inference, MI355X-native (mirrors the GPU side of the reference's
 scripts/aerial_image_segmentation_api.py -- SURVEY.md 8f row N2 / BASELINE config 5).
 
-In scope (GPU): the eval-mode generator forward over all patches of an image.  The reference runs one
-patch per forward (`api.py:385-390`); here patches are batched and every BasicBlock runs as three MFMA
-launches with its batch norms folded in, then one sigmoid kernel -- same values, no per-patch sync.
-Host side kept: the patch order of `patch_gen` (4 corner-anchored sweeps, `api.py:45-116`) and the
-overlap-averaging of `patch_merge` (`api.py:119-217`) without its cv2-dependent resize/hysteresis steps
-(cv2 and albumentations are host-only dependencies that this package does not take on).
+GPU side: the eval-mode generator forward over all patches of an image.  The reference runs one patch per forward
+(`api.py:385-390`); here patches are batched and every BasicBlock runs as three MFMA launches with its batch norms folded
+in, then one sigmoid kernel -- same values, no per-patch sync.
+
+Host side (numpy, no cv2 / albumentations -- neither is installed here, and the package takes on no host dependency for
+them): `load_segmentation_models` (`api.py:302-333`), `get_patched_input` (`api.py:336-373`, including its double
+normalisation: albumentations `Normalize()` and THEN `/ 255` again, `:354-367`), the patch order of `patch_gen`
+(`api.py:45-116`), `patch_merge` with its uint8 round trip, 2x resize and threshold post-processing (`api.py:33-42,119-217`)
+and `mask_convert` (`api.py:218-234`).  What replaces the two library calls, and how it is pinned:
+  * `cv2.resize` (default INTER_LINEAR) is restated for the two exact factors the pipeline uses -- 1/2 (1024 -> 512: the
+    half-pixel-centre bilinear kernel is exactly the 2x2 box mean) and 2 (512 -> 1024: 0.25 / 0.75 taps, edge-clamped),
+    rounded half up like OpenCV's fixed-point path; any other factor raises.  cv2 is absent from this environment, so
+    this restatement is NOT pinned by a reference-generated vector (OpenCV's two-pass fixed-point rounding can differ by
+    one grey level); downstream of `patch_merge` every resized value is thresholded at 127, so a one-level difference
+    matters only for interpolated values of exactly 127 or 128.
+  * albumentations `Normalize()` defaults (mean (0.485, 0.456, 0.406), std (0.229, 0.224, 0.225), max_pixel_value 255) in
+    its float32 arithmetic order; applied, as the reference does, to the BGR channel order `cv2.imread` yields.
 """
+import json
 import math
+import os
 
 import numpy as np
 import torch
 
-from . import ops
+from . import archs, ops
 
 
 def patch_origins(img_h, img_w, p_size, overlap=0.5):
@@ -39,16 +52,54 @@ def patch_gen(img, mask, p_size, overlap=0.5):
     return ([img[h:h + p_size, w:w + p_size, :] for h, w in org], [mask[h:h + p_size, w:w + p_size, :] for h, w in org])
 
 
-def infer_patches(model, img_patch_set, batch_size=16):
+_GRAPHS = {}
+
+
+def _graph_for(model, shape, device):
+    """hipGraph of `sigmoid(model(x))` for one input shape (eval mode).  At batch 1 the forward is ~330 kernel launches of
+    a few microseconds each, issued through Python + ctypes: the launch path, not the GPU, sets the patch rate.  Captured
+    once (after a warm-up call that fills the packed-weight and BN-fold caches), a patch is one graph launch.  The graph is
+    tied to the parameter values it was captured with: it is keyed by the weight / statistics epochs."""
+    key = (id(model), tuple(shape), str(device), ops._WEIGHT_EPOCH[0], ops._STATS_EPOCH[0])
+    hit = _GRAPHS.get(key)
+    if hit is not None and hit[0]() is model:
+        return hit[1:]
+    import weakref
+    static_in = torch.zeros(shape, dtype=torch.float32, device=device)
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):                       # warm-up on the capture stream: caches, lazy kernel attributes
+        ops.sigmoid(model(static_in))
+    torch.cuda.current_stream(device).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_out = ops.sigmoid(model(static_in))
+    for k in [k for k, v in _GRAPHS.items() if v[0]() is None or (k[0] == id(model) and k[1] == tuple(shape))]:
+        del _GRAPHS[k]                                  # stale captures of this model / dead models
+    _GRAPHS[key] = (weakref.ref(model), graph, static_in, static_out)
+    return graph, static_in, static_out
+
+
+def infer_patches(model, img_patch_set, batch_size=16, graph=None):
     """sigmoid(model(patch)) for every patch, batched.  img_patch_set: [P, C, H, W] float32 (numpy or
-    tensor, as `get_patched_input` builds it); returns a float32 tensor [P, num_classes, H, W] on the host."""
+    tensor, as `get_patched_input` builds it); returns a float32 tensor [P, num_classes, H, W] on the host.
+    `graph`: replay a captured hipGraph per batch instead of launching kernel by kernel (default: on for batch_size <= 2,
+    where the forward is launch-bound; the reference's own loop is batch_size 1, api.py:385-390)."""
     x = torch.as_tensor(img_patch_set, dtype=torch.float32)
     model.eval()
+    if graph is None:
+        graph = batch_size <= 2
     outs = []
     with torch.no_grad():
         for i in range(0, x.shape[0], batch_size):
             xb = x[i:i + batch_size].cuda(non_blocking=True)
-            y = ops.sigmoid(model(xb))
+            if graph:
+                g, static_in, static_out = _graph_for(model, xb.shape, xb.device)
+                static_in.copy_(xb)
+                g.replay()
+                y = static_out.clone()
+            else:
+                y = ops.sigmoid(model(xb))
             outs.append(y)
     out = torch.cat([o.contiguous() for o in outs], 0) if len(outs) > 1 else outs[0].contiguous()
     return out.cpu()
@@ -78,3 +129,147 @@ def segmentation_inference(model, img_input, img_patch_set, mask_patch_set, conf
     all_class_mask = patch_merge_mean(img_input.shape[0], img_input.shape[1], list(probs), config['patch_size'],
                                       config['patch_overlap'], config['num_classes'])
     return all_class_mask, all_class_mask
+
+
+# ----------------------------------------------------------------------------- host half (api.py:33-42,218-234,302-373)
+def post_process_resized_mask(resized_mask):
+    """api.py:33-42: values in (127, 255) -> 255, values in (0, 127] -> 0 (in place, like the reference)."""
+    half_th = 127
+    resized_mask[(resized_mask > half_th) & (resized_mask < 255)] = 255
+    resized_mask[(resized_mask > 0) & (resized_mask <= half_th)] = 0
+    return resized_mask
+
+
+def resize_u8(img, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h)) (INTER_LINEAR) for uint8 images at the exact factors 1, 1/2 and 2 (module docstring)."""
+    img = np.asarray(img)
+    if img.dtype != np.uint8:
+        raise TypeError('resize_u8 expects uint8')
+    h, w = img.shape[:2]
+    if (out_h, out_w) == (h, w):
+        return img.copy()
+    if h == 2 * out_h and w == 2 * out_w:                 # src = 2*dst + 0.5: mean of a 2x2 box
+        a = img.astype(np.uint16)
+        s4 = a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2]
+        return ((s4 + 2) >> 2).astype(np.uint8)
+    if out_h == 2 * h and out_w == 2 * w:                 # src = dst/2 - 0.25: taps (0.25, 0.75) / (0.75, 0.25), clamped at the edges
+        def up(a, axis):
+            a = np.moveaxis(a, axis, 0)
+            prev = np.concatenate([a[:1], a[:-1]], 0); nxt = np.concatenate([a[1:], a[-1:]], 0)
+            out = np.empty((2 * a.shape[0],) + a.shape[1:], dtype=np.float64)
+            out[0::2] = 0.25 * prev + 0.75 * a
+            out[1::2] = 0.75 * a + 0.25 * nxt
+            return np.moveaxis(out, 0, axis)
+        f = up(up(img.astype(np.float64), 0), 1)
+        return np.floor(f + 0.5).astype(np.uint8)
+    raise NotImplementedError('resize_u8: only the exact factors 1, 1/2 and 2 of the sliding-window pipeline are restated '
+                              '(%dx%d -> %dx%d needs cv2.resize)' % (h, w, out_h, out_w))
+
+
+def normalize_imagenet(img):
+    """albumentations.Normalize() with its defaults on an HxWx3 uint8 image, float32 arithmetic in its order."""
+    mean = np.array((0.485, 0.456, 0.406), dtype=np.float32) * 255.0
+    std = np.array((0.229, 0.224, 0.225), dtype=np.float32) * 255.0
+    denom = np.reciprocal(std, dtype=np.float32)
+    out = img.astype(np.float32)
+    out -= mean
+    out *= denom
+    return out
+
+
+def imread_bgr(path):
+    """cv2.imread(path): HxWx3 uint8 in BGR order (decoded with PIL)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert('RGB'))
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def get_patched_input(img_path, config, gt_mask_flag, imread=imread_bgr):
+    """api.py:336-373.  Returns (img_input, img_patch_set [P, 3, input_w, input_w] float32, mask_patch_set)."""
+    p_size, img_size, patch_overlap = config['patch_size'], config['input_w'], config['patch_overlap']
+    img_input = imread(img_path)
+    mask_input = imread(img_path.replace('image', 'labels')) if gt_mask_flag is True else img_input
+    image_patch, mask_patch = patch_gen(img_input, mask_input, p_size, patch_overlap)
+    if (config['input_h'], config['input_w']) != (img_size, img_size):
+        raise NotImplementedError('non-square inference size')
+    img_patch_set = []
+    for img in image_patch:
+        img = resize_u8(img, img_size, img_size)                     # :359; the Resize() of the transform is then the identity
+        img = normalize_imagenet(img)                                # :364-365 (transforms.Normalize())
+        img = img.astype('float32') / 255                            # :367 -- yes, a second division by 255
+        img_patch_set.append(img.transpose(2, 0, 1))
+    return img_input, np.array(img_patch_set), np.array(mask_patch)
+
+
+def mask_convert(p_mask, idx, p_size):
+    """api.py:218-234: class idx of a BGR label patch -> {0, 255} mask at p_size."""
+    want = {0: (255, 255, 255), 1: (255, 0, 0), 2: (0, 0, 255)}[idx]
+    sel = (p_mask[:, :, 0] == want[0]) & (p_mask[:, :, 1] == want[1]) & (p_mask[:, :, 2] == want[2])
+    mask = (sel.astype(np.float64) * 255).astype('uint8')
+    return post_process_resized_mask(resize_u8(mask, p_size, p_size))
+
+
+def patch_merge(img, masks, p_size, config, p_overlap):
+    """api.py:119-217: per class, every patch's probability map -> uint8 -> resized to p_size -> thresholded -> overlap
+    average -> uint8 -> thresholded again.  Returns a list of num_classes uint8 [H, W] masks with values {0, 255}."""
+    img_h, img_w = img.shape[0], img.shape[1]
+    org = patch_origins(img_h, img_w, p_size, p_overlap)
+    if len(org) != len(masks):
+        raise ValueError('expected %d patches, got %d' % (len(org), len(masks)))
+    all_class_mask = []
+    for c in range(config['num_classes']):
+        merged = np.zeros((img_h, img_w)); div = np.zeros((img_h, img_w))
+        for (h1, w1), m in zip(org, masks):
+            mask = (np.asarray(m[c]) * 255).astype('uint8')
+            resized = post_process_resized_mask(resize_u8(mask, p_size, p_size)) / 255.0
+            merged[h1:h1 + p_size, w1:w1 + p_size] += resized
+            div[h1:h1 + p_size, w1:w1 + p_size] += 1.0
+        div[div == 0] = 1.0
+        full = (np.divide(merged, div) * 255).astype('uint8')
+        all_class_mask.append(post_process_resized_mask(full))
+    return all_class_mask
+
+
+def load_segmentation_models(config_file):
+    """api.py:302-333: read <model_path>/<name>/config.yml, build archs[config['arch']], load model.pth, eval mode; force
+    patch_size 1024 and take patch_overlap from val_config."""
+    import yaml
+    config_dict = json.loads(open(config_file, 'rt').read())
+    file_dict, val_config = config_dict['file_path'], config_dict['val_config']
+    model_folder, name = file_dict['model_path'], val_config['name']
+    with open(os.path.join(model_folder, '%s/config.yml' % name), 'r') as f:
+        config = yaml.load(f, Loader=yaml.FullLoader)
+    config['name'] = name
+    print('-' * 20)
+    for key in config.keys():
+        print('%s: %s' % (key, str(config[key])))
+    print('-' * 20)
+    print("=> creating model %s" % config['arch'])
+    if config['arch'] not in archs.__all__:
+        raise NotImplementedError('arch %r is not built in ssunet-gan_amd' % config['arch'])
+    model = archs.__dict__[config['arch']](config['num_classes'], config['input_channels'], config['deep_supervision'])
+    model = model.cuda()
+    state = torch.load(os.path.join(model_folder, '%s/model.pth' % config['name']), map_location='cpu')
+    model.load_state_dict(state)
+    model.eval()
+    config['patch_size'] = 1024
+    config['patch_overlap'] = val_config['patch_overlap']
+    return model, config
+
+
+def segmentation_inference_full(model, img_input, img_patch_set, mask_patch_set, config, gt_mask_flag, batch_size=12):
+    """api.py:376-410 complete: (all_class_mask, gt_class_mask) as lists of uint8 {0, 255} masks at image resolution.  The model
+    forward is batched (`batch_size` patches per launch sequence; 1 = the reference's loop)."""
+    patch_size, infer_size, p_overlap = config['patch_size'], config['input_w'], config['patch_overlap']
+    full_output = list(infer_patches(model, img_patch_set, batch_size).numpy())
+    all_class_mask = patch_merge(img_input, full_output, patch_size, config, p_overlap)
+    if gt_mask_flag is True:
+        gt_label = []
+        for data in mask_patch_set:
+            m = np.dstack([mask_convert(data, c, infer_size) for c in range(config['num_classes'])]).transpose(2, 0, 1)
+            gt_label.append(m / 255.0)
+        gt_class_mask = patch_merge(img_input, gt_label, patch_size, config, p_overlap)
+    else:
+        gt_class_mask = all_class_mask
+    return all_class_mask, gt_class_mask

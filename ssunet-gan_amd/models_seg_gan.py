@@ -40,6 +40,10 @@ class ConvolutionalBlock(nn.Module):
 
     def forward(self, input):
         conv = self.conv_block[0]
+        # The conv runs through ops.conv2d on conv.weight, not through nn.Conv2d.__call__: forward pre-hooks registered on the
+        # conv module (spectral_norm re-parametrises `weight` in one: spectral_norm.py:99-101) are honoured here.
+        for hook in conv._forward_pre_hooks.values():
+            hook(conv, (input,))
         if self._act not in (None, 'leakyrelu'):
             raise NotImplementedError('ConvolutionalBlock activation %r has no HIP path (only the discriminator\'s '
                                       'LeakyReLU flavour is on the hot path)' % self._act)

@@ -13,6 +13,10 @@ from . import ops
 
 
 class SpectralNorm(object):
+    # spectral_norm.py:13-18: version 1 = `weight` is recomputed from `weight_orig`, `weight_u`, `weight_v` in every forward
+    # and is not part of the state_dict; an unversioned checkpoint also carries `weight` and no `weight_v`.
+    _version = 1
+
     def __init__(self, name='weight', n_power_iterations=1, dim=0, eps=1e-12):
         if n_power_iterations <= 0:
             raise ValueError('Expected n_power_iterations to be positive, but got n_power_iterations={}'.format(n_power_iterations))
@@ -65,7 +69,46 @@ class SpectralNorm(object):
         module.register_buffer(fn.name + '_u', u)
         module.register_buffer(fn.name + '_v', v)
         module.register_forward_pre_hook(fn)
+        module._register_state_dict_hook(_StateDictVersion(fn))
+        module._register_load_state_dict_pre_hook(_LoadUnversioned(fn))
         return fn
+
+
+class _StateDictVersion(object):
+    """spectral_norm.py:179-189: stamp `<name>.version` into the module's state_dict metadata."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, module, state_dict, prefix, local_metadata):
+        meta = local_metadata.setdefault('spectral_norm', {})
+        key = self.fn.name + '.version'
+        if key in meta:
+            raise RuntimeError("Unexpected key in metadata['spectral_norm']: {}".format(key))
+        meta[key] = self.fn._version
+
+
+class _LoadUnversioned(object):
+    """spectral_norm.py:147-174: a checkpoint written before version 1 holds (weight_orig, weight, weight_u) and no weight_v.
+    Recover v from the invariant u = normalize(W_orig v), sigma = u^T W_orig v with sigma = mean(W_orig / W) (pseudo-inverse
+    solve, spectral_norm.py:102-107), and drop the stale `weight` entry.  Host-side checkpoint conversion: plain torch."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        fn = self.fn
+        version = local_metadata.get('spectral_norm', {}).get(fn.name + '.version', None)
+        if version is not None and version >= 1:
+            return
+        with torch.no_grad():
+            w_orig = state_dict[prefix + fn.name + '_orig']
+            w = state_dict.pop(prefix + fn.name)
+            sigma = (w_orig / w).mean()
+            wm = fn.reshape_weight_to_matrix(w_orig)
+            u = state_dict[prefix + fn.name + '_u']
+            v = torch.linalg.multi_dot([torch.linalg.pinv(wm.t().mm(wm)), wm.t(), u.unsqueeze(1)]).squeeze(1)
+            state_dict[prefix + fn.name + '_v'] = v * (sigma / torch.dot(u, torch.mv(wm, v)))
 
 
 def spectral_norm(module, name='weight', n_power_iterations=1, eps=1e-12, dim=None):
