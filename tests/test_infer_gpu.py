@@ -134,7 +134,9 @@ def test_full_size_2048_image_36_patches(pkg, dev, tmp_path):
     for (k, a), (_, b) in zip(model.state_dict().items(), src.state_dict().items()):
         assert torch.equal(a, b), k
     rng = np.random.default_rng(5)
-    img = (rng.integers(0, 256, (128, 128, 3)).repeat(16, 0).repeat(16, 1)).astype(np.uint8)      # 2048^2, blocky
+    # per-pixel noise: exactly flat regions would put exact ties into every 2x2 max-pool window, where two implementations
+    # may legitimately pick different argmax positions (the indices feed max-unpool)
+    img = rng.integers(0, 256, (2048, 2048, 3), dtype=np.uint8)
     p = str(tmp_path / 'image_1.png')
     _write_png(p, img)
     full, patches, masks = A.get_patched_input(p, config, False)
@@ -149,7 +151,8 @@ def test_full_size_2048_image_36_patches(pkg, dev, tmp_path):
     Go.eval()
     with torch.no_grad():
         ref = torch.sigmoid(Go(torch.from_numpy(patches[[0, 17]]))).numpy()
-    assert np.abs(ref - probs12[[0, 17]]).max() < 5e-5
+    err = np.abs(ref - probs12[[0, 17]])
+    assert err.max() < 5e-5, 'vs CPU oracle: max %.3e median %.3e' % (err.max(), np.median(err))
     all_mask, gt_mask = A.segmentation_inference_full(model, full, patches, masks, config, False, batch_size=12)
     assert len(all_mask) == 3 and all_mask[1].shape == (2048, 2048) and all_mask[1].dtype == np.uint8
     assert set(np.unique(all_mask[1])) <= {0, 255} and gt_mask is all_mask

@@ -37,6 +37,16 @@ def main():
         dt = timed(lambda: S.aerial_image_segmentation_api.infer_patches(G, patches, batch_size=bs), 1, 3)
         out.append({'what': 'C5 sliding-window inference, 36 x 3x512x512 patches, eval-mode G (BN folded), batch %d, incl. H2D/D2H' % bs,
                     'patches_per_s': round(36 / dt, 2), 's_per_image': round(dt, 3)})
+    # batch 1 on resident inputs: kernel-by-kernel launches vs hipGraph replay (what the launch path costs at batch 1)
+    xb = patches[:1].to(dev)
+    G.eval()
+    with torch.no_grad():
+        dt_eager = timed(lambda: S.ops.sigmoid(G(xb)), 3, 20)
+        gr, sin, sout = S.aerial_image_segmentation_api._graph_for(G, xb.shape, dev)
+        sin.copy_(xb)
+        dt_graph = timed(lambda: gr.replay(), 3, 20)
+    out.append({'what': 'C5 one 3x512x512 patch, eval-mode G, input resident: eager launches vs hipGraph replay',
+                'ms_eager': round(dt_eager * 1e3, 3), 'ms_graph': round(dt_graph * 1e3, 3)})
     # N1: stage-1 trainer step (G only, BCEDice, weight clamp, Adam with weight decay)
     cfg = {'clip': 0.7, 'num_classes': 3, 'deep_supervision': False}
     model = S.archs.UNet_R_SS_v2(3, 3, False).to(dev)
