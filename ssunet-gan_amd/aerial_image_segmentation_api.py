@@ -56,10 +56,13 @@ _GRAPHS = {}
 
 
 def _graph_for(model, shape, device):
-    """hipGraph of `sigmoid(model(x))` for one input shape (eval mode).  At batch 1 the forward is ~330 kernel launches of
-    a few microseconds each, issued through Python + ctypes: the launch path, not the GPU, sets the patch rate.  Captured
-    once (after a warm-up call that fills the packed-weight and BN-fold caches), a patch is one graph launch.  The graph is
-    tied to the parameter values it was captured with: it is keyed by the weight / statistics epochs."""
+    """hipGraph of `sigmoid(model(x))` for one input shape (eval mode), captured after a warm-up call that fills the
+    packed-weight and BN-fold caches; tied to the parameter values it was captured with (keyed by the weight / statistics
+    epochs).  MEASURED (profiles/r02_a_bench_extra.jsonl): one 3x512x512 patch takes 6.52 ms launched kernel by kernel and
+    6.48 ms as a graph replay -- the ~330 launches of a batch-1 forward are NOT what limits the patch rate (round 1 assumed
+    so); the deep levels do (16x16 x 768 channels at batch 1 is 12 workgroups of 432 K-steps on a 256-CU chip).  The graph
+    path is therefore opt-in (`graph=True`), kept because it takes the Python launch path off the host for callers that
+    overlap other host work."""
     key = (id(model), tuple(shape), str(device), ops._WEIGHT_EPOCH[0], ops._STATS_EPOCH[0])
     hit = _GRAPHS.get(key)
     if hit is not None and hit[0]() is model:
@@ -80,15 +83,12 @@ def _graph_for(model, shape, device):
     return graph, static_in, static_out
 
 
-def infer_patches(model, img_patch_set, batch_size=16, graph=None):
+def infer_patches(model, img_patch_set, batch_size=16, graph=False):
     """sigmoid(model(patch)) for every patch, batched.  img_patch_set: [P, C, H, W] float32 (numpy or
     tensor, as `get_patched_input` builds it); returns a float32 tensor [P, num_classes, H, W] on the host.
-    `graph`: replay a captured hipGraph per batch instead of launching kernel by kernel (default: on for batch_size <= 2,
-    where the forward is launch-bound; the reference's own loop is batch_size 1, api.py:385-390)."""
+    `graph=True`: replay a captured hipGraph per batch instead of launching kernel by kernel (same values; see _graph_for)."""
     x = torch.as_tensor(img_patch_set, dtype=torch.float32)
     model.eval()
-    if graph is None:
-        graph = batch_size <= 2
     outs = []
     with torch.no_grad():
         for i in range(0, x.shape[0], batch_size):

@@ -17,9 +17,10 @@ constexpr int MAX_PARTS = 1024;
 
 struct RedGeom { int TQ, PR, groups, parts; long long rows_per_part; };
 
-__host__ RedGeom red_geom(long long P, int C) {
+// Q = channel quads per thread (1: fp32 and every 4-channel-granular caller; 2: bf16 with C % 8 == 0)
+__host__ RedGeom red_geom(long long P, int C, int Q = 1) {
   RedGeom g;
-  const int CQ = (C + 3) / 4;
+  const int CQ = (C + 4 * Q - 1) / (4 * Q);
   g.TQ = CQ >= 64 ? 64 : 1;
   if (CQ < 64) { while (g.TQ < CQ) g.TQ <<= 1; }
   g.PR = RED_BLOCK / g.TQ;
@@ -38,68 +39,88 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
     const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, long long P, int C,
     int ldx, int ldy, int lddy, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope,
-    int TQ, int PR, long long rows_per_part, double* __restrict__ part /* [parts][2][Cq4] */) {
-  __shared__ double red[2][RED_BLOCK][4];
+    int TQ, int PR, long long rows_per_part, double* __restrict__ part /* [parts][2][Cpad] */) {
+  constexpr int Q = SsgQ<T>::value;              // channel quads per 16-byte access
+  constexpr int V = 4 * Q;
+  __shared__ double red[2][RED_BLOCK][V];
   const int tid = threadIdx.x;
   const int tq = tid % TQ, pr = tid / TQ;
-  const int cq = blockIdx.y * TQ + tq;
-  const int CQ = (C + 3) / 4;
-  const bool cok = cq < CQ;
+  const int cg = blockIdx.y * TQ + tq;           // channel group of V channels
+  const int CG = (C + V - 1) / V;
+  const bool cok = cg < CG;
   const long long p0 = (long long)blockIdx.x * rows_per_part;
   long long p1 = p0 + rows_per_part; if (p1 > P) p1 = P;
   // fp64 accumulators: var = E[x^2] - mean^2 cancels catastrophically in fp32 for channels whose
   // variance is far below mean^2 (deep layers with few pixels); x*x is exact in fp64.
-  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
+  double s1[V], s2[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { s1[e] = 0; s2[e] = 0; }
+  float mu[V], is[V], sc[V], sh[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mu[e] = 0.f; is[e] = 0.f; sc[e] = 0.f; sh[e] = 0.f; }
   if (MODE == 1 && cok) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = 4 * cq + e;
-      if (c < C) { mu[e] = mean[c]; is[e] = invstd[c]; if (!y && scale) { sc[e] = scale[c]; sh[e] = shift[c]; } }
+    for (int e = 0; e < V; ++e) {
+      const int c = V * cg + e;
+      if (c < C) { mu[e] = mean[c]; is[e] = invstd[c]; if ((!y || act == SSG_ACT_SWISH) && scale) { sc[e] = scale[c]; sh[e] = shift[c]; } }
     }
   }
   if (cok) {
     for (long long p = p0 + pr; p < p1; p += PR) {
-      const f32x4 xv = ld4(x + p * ldx + 4 * cq);
+      f32x4 xq[Q];
+      ldq(x + p * ldx + V * cg, xq);
       if (MODE == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const double v = (double)xv[e]; s1[e] += v; s2[e] += v * v; }
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const double v = (double)xq[q][e]; s1[4 * q + e] += v; s2[4 * q + e] += v * v; }
       } else if (MODE == 2) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s1[e] += (double)xv[e];
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s1[4 * q + e] += (double)xq[q][e];
       } else {
-        f32x4 g = ld4(dy + p * lddy + 4 * cq);
-        if (act == SSG_ACT_SWISH) {
-          // smooth activation: its derivative is a function of the pre-activation z = x*scale + shift (recomputed)
-          const f32x4 z = xv * sc + sh;
+        f32x4 gq[Q], yq[Q];
+        ldq(dy + p * lddy + V * cg, gq);
+        const bool use_y = act != SSG_ACT_NONE && act != SSG_ACT_SWISH && y;
+        if (use_y) ldq(y + p * ldy + V * cg, yq);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] *= ssg_swish_grad(z[e]);
-        } else if (act != SSG_ACT_NONE) {
-          // activation mask: from the saved output, or -- when the forward had no residual -- recomputed with
-          // the forward's own expression x*scale + shift (same fp32 fma, same inputs: bitwise the same sign)
-          const f32x4 yv = y ? ld4(y + p * ldy + 4 * cq) : xv * sc + sh;
+        for (int q = 0; q < Q; ++q) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) g[e] *= (act == SSG_ACT_RELU ? 0.f : slope);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const double xh = ((double)xv[e] - (double)mu[e]) * (double)is[e];
-          s1[e] += (double)g[e]; s2[e] += (double)g[e] * xh;
+          for (int e = 0; e < 4; ++e) {
+            const int k = 4 * q + e;
+            float g = gq[q][e];
+            const float xv = xq[q][e];
+            if (act == SSG_ACT_SWISH) {
+              // smooth activation: its derivative is a function of the pre-activation z = x*scale + shift (recomputed)
+              g *= ssg_swish_grad(xv * sc[k] + sh[k]);
+            } else if (act != SSG_ACT_NONE) {
+              // activation mask: from the saved output, or -- when the forward had no residual -- recomputed with
+              // the forward's own expression x*scale + shift (same fp32 fma, same inputs: bitwise the same sign)
+              const float yv = use_y ? yq[q][e] : xv * sc[k] + sh[k];
+              if (!(yv > 0.f)) g *= (act == SSG_ACT_RELU ? 0.f : slope);
+            }
+            const double xh = ((double)xv - (double)mu[k]) * (double)is[k];
+            s1[k] += (double)g; s2[k] += (double)g * xh;
+          }
         }
       }
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+  for (int e = 0; e < V; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
   __syncthreads();
   if (pr == 0 && cok) {
-    double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    double a1[V], a2[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { a1[e] = 0; a2[e] = 0; }
     for (int r = 0; r < PR; ++r)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a1[e] += red[0][r * TQ + tq][e]; a2[e] += red[1][r * TQ + tq][e]; }
-    double* dst = part + (size_t)blockIdx.x * 2 * (4 * CQ);
+      for (int e = 0; e < V; ++e) { a1[e] += red[0][r * TQ + tq][e]; a2[e] += red[1][r * TQ + tq][e]; }
+    const int Cpad = V * CG;
+    double* dst = part + (size_t)blockIdx.x * 2 * Cpad;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { dst[4 * cq + e] = a1[e]; dst[4 * CQ + 4 * cq + e] = a2[e]; }
+    for (int e = 0; e < V; ++e) { dst[V * cg + e] = a1[e]; dst[Cpad + V * cg + e] = a2[e]; }
   }
 }
 
@@ -205,17 +226,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const T* __restrict__ res, int ldr, int act, float slope,
                                                        T* __restrict__ y, int ldy) {
-  const int CQ = C / 4;
-  const long long total = P * CQ;
+  constexpr int Q = SsgQ<T>::value;          // channel quads per 16-byte access
+  const int CG = C / (4 * Q);
+  const long long total = P * CG;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
-    const f32x4 xv = ld4(x + p * ld + 4 * cq);
-    const f32x4 sc = *(const f32x4*)(scale + 4 * cq), sh = *(const f32x4*)(shift + 4 * cq);
-    f32x4 v = xv * sc + sh;
-    if (res) v += ld4(res + p * ldr + 4 * cq);
+    const long long p = i / CG; const int c0 = 4 * Q * (int)(i - p * CG);
+    f32x4 xv[Q], rv[Q], o[Q];
+    ldq(x + p * ld + c0, xv);
+    if (res) ldq(res + p * ldr + c0, rv);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = ssg_act(v[e], act, slope);
-    st4(y + p * ldy + 4 * cq, v);
+    for (int q = 0; q < Q; ++q) {
+      const f32x4 sc = *(const f32x4*)(scale + c0 + 4 * q), sh = *(const f32x4*)(shift + c0 + 4 * q);
+      f32x4 v = xv[q] * sc + sh;
+      if (res) v += rv[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ssg_act(v[e], act, slope);
+      o[q] = v;
+    }
+    stq(y + p * ldy + c0, o);
   }
 }
 
@@ -226,9 +254,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ scale, const float* __restrict__ shift,
     const double* __restrict__ sums, double count_arg, int act, float slope, T* __restrict__ dx, int lddx,
     T* __restrict__ dres, int lddres, float* __restrict__ dweight, float* __restrict__ dbias) {
-  const int CQ = C / 4;
   const double count = count_arg > 0 ? count_arg : sums[2 * C];
-  const long long total = P * CQ;
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += 256) {
       if (dweight) dweight[c] = (float)sums[C + c];
@@ -244,35 +270,48 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     k_m1[c] = sums[c] / count; k_m2[c] = sums[C + c] / count;
   }
   __syncthreads();
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long p = i / CQ; const int cq = (int)(i - p * CQ);
-    f32x4 g = ld4(dy + p * lddy + 4 * cq);
-    const f32x4 xv = ld4(x + p * ldx + 4 * cq);
-    if (act == SSG_ACT_SWISH) {
-      const f32x4 z = xv * *(const f32x4*)(scale + 4 * cq) + *(const f32x4*)(shift + 4 * cq);
+  constexpr int Q = SsgQ<T>::value;
+  const int CG = C / (4 * Q);
+  const long long totalg = P * CG;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < totalg; i += (long long)gridDim.x * 256) {
+    const long long p = i / CG; const int c0 = 4 * Q * (int)(i - p * CG);
+    f32x4 gq[Q], xq[Q], yq[Q], oq[Q];
+    ldq(dy + p * lddy + c0, gq);
+    ldq(x + p * ldx + c0, xq);
+    const bool use_y = act != SSG_ACT_NONE && act != SSG_ACT_SWISH && y;
+    if (use_y) ldq(y + p * ldy + c0, yq);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] *= ssg_swish_grad(z[e]);
-    } else if (act != SSG_ACT_NONE) {
-      const f32x4 yv = y ? ld4(y + p * ldy + 4 * cq)
-                         : xv * *(const f32x4*)(scale + 4 * cq) + *(const f32x4*)(shift + 4 * cq);
+    for (int q = 0; q < Q; ++q) {
+      const int cb = c0 + 4 * q;
+      f32x4 g = gq[q];
+      const f32x4 xv = xq[q];
+      if (act == SSG_ACT_SWISH) {
+        const f32x4 z = xv * *(const f32x4*)(scale + cb) + *(const f32x4*)(shift + cb);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) g[e] *= (act == SSG_ACT_RELU ? 0.f : slope);
-    }
-    if (dres) st4(dres + p * lddres + 4 * cq, g);
-    if (dx) {
-      f32x4 o;
-      // fp64 arithmetic, as ATen's CPU batch-norm backward (accscalar = double for float tensors):
-      // g - mean(g) - xhat*mean(g*xhat) cancels heavily, and an fp32-rounded per-channel constant
-      // would add the SAME error to every pixel (a coherent bias that the next dgrad/bias-grad
-      // sums amplify).  The kernel is HBM-bound; fp64 VALU work is free here.
+        for (int e = 0; e < 4; ++e) g[e] *= ssg_swish_grad(z[e]);
+      } else if (act != SSG_ACT_NONE) {
+        const f32x4 yv = use_y ? yq[q] : xv * *(const f32x4*)(scale + cb) + *(const f32x4*)(shift + cb);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = 4 * cq + e;
-        const double xh = ((double)xv[e] - k_mean[c]) * k_is[c];
-        o[e] = (float)(k_ws[c] * ((double)g[e] - k_m1[c] - xh * k_m2[c]));
+        for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) g[e] *= (act == SSG_ACT_RELU ? 0.f : slope);
       }
-      st4(dx + p * lddx + 4 * cq, o);
+      gq[q] = g;
+      if (dx) {
+        f32x4 o;
+        // fp64 arithmetic, as ATen's CPU batch-norm backward (accscalar = double for float tensors):
+        // g - mean(g) - xhat*mean(g*xhat) cancels heavily, and an fp32-rounded per-channel constant
+        // would add the SAME error to every pixel (a coherent bias that the next dgrad/bias-grad
+        // sums amplify).  The kernel is HBM-bound; fp64 VALU work is free here.
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = cb + e;
+          const double xh = ((double)xv[e] - k_mean[c]) * k_is[c];
+          o[e] = (float)(k_ws[c] * ((double)g[e] - k_m1[c] - xh * k_m2[c]));
+        }
+        oq[q] = o;
+      }
     }
+    if (dres) stq(dres + p * lddres + c0, gq);
+    if (dx) stq(dx + p * lddx + c0, oq);
   }
 }
 
@@ -288,8 +327,9 @@ int run_reduce(const T* x, const T* y, const T* dy, long long P, int C, int ldx,
                const float* scale, const float* shift,
                const float* mean, const float* invstd, int act, float slope, double* sums, float* fsum, void* ws,
                hipStream_t st, double count_out = 0.0) {
-  const RedGeom g = red_geom(P, C);
-  const int C4 = 4 * ((C + 3) / 4);
+  constexpr int Q = SsgQ<T>::value;
+  const RedGeom g = red_geom(P, C, Q);
+  const int C4 = 4 * Q * ((C + 4 * Q - 1) / (4 * Q));
   double* part = (double*)ws;
   hipLaunchKernelGGL((col_reduce_kernel<MODE, T>), dim3((unsigned)g.parts, (unsigned)g.groups), dim3(RED_BLOCK), 0, st, x, y, dy,
                      P, C, ldx, ldy, lddy, mean, invstd, scale, shift, act, slope, g.TQ, g.PR, g.rows_per_part, part);
@@ -311,7 +351,8 @@ namespace {
 template <typename T>
 int bn_stats_impl(const T* x, int64_t P, int C, int ld, double* sums, int with_count, void* ws, void* stream) {
   SSG_REQUIRE(x && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_stats: bad args");
-  SSG_REQUIRE(ld % 4 == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN, "bn_stats: alignment");
+  SSG_REQUIRE(C % (4 * SsgQ<T>::value) == 0 && ld % (4 * SsgQ<T>::value) == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN,
+              "bn_stats: C / ld must be multiples of 4 (fp32) or 8 (bf16), rows 16-byte aligned");
   return run_reduce<0, T>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, sums, nullptr, ws, (hipStream_t)stream,
                           with_count ? (double)P : 0.0);
 }
@@ -320,9 +361,11 @@ template <typename T>
 int bn_apply_impl(const T* x, int64_t P, int C, int ld, const float* scale, const float* shift, const T* res, int ldr, int act, float slope,
                   T* y, int ldy, void* stream) {
   SSG_REQUIRE(x && y && scale && shift && P > 0 && C > 0, SSG_EINVAL, "bn_apply: bad args");
-  SSG_REQUIRE(C % 4 == 0 && ld % 4 == 0 && ldy % 4 == 0 && (!res || ldr % 4 == 0), SSG_EALIGN, "bn_apply: C/ld multiples of 4");
+  constexpr int G = 4 * SsgQ<T>::value;
+  SSG_REQUIRE(C % G == 0 && ld % G == 0 && ldy % G == 0 && (!res || ldr % G == 0) && ssg_aligned16(x) && ssg_aligned16(y) && (!res || ssg_aligned16(res)),
+              SSG_EALIGN, "bn_apply: C/ld must be multiples of 4 (fp32) or 8 (bf16), rows 16-byte aligned");
   SSG_REQUIRE(!(act == SSG_ACT_SWISH && res), SSG_EINVAL, "bn_apply: swish with a residual is not supported (its backward needs the pre-activation)");
-  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, (long long)P, C, ld,
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((unsigned)elem_grid(P * (C / (4 * SsgQ<T>::value)))), dim3(256), 0, (hipStream_t)stream, x, (long long)P, C, ld,
                      scale, shift, res, ldr, act, slope, y, ldy);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
@@ -335,7 +378,8 @@ int bn_bwd_reduce_impl(const T* x, const T* y, const T* dy, int64_t P, int C, in
   SSG_REQUIRE(x && dy && mean && invstd && sums && ws && P > 0 && C > 0, SSG_EINVAL, "bn_bwd_reduce: bad args");
   SSG_REQUIRE(act == SSG_ACT_NONE || (y && act != SSG_ACT_SWISH) || (scale && shift), SSG_EINVAL,
               "bn_bwd_reduce: activation gradient needs y (ReLU family only) or (scale, shift)");
-  SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_reduce: alignment");
+  SSG_REQUIRE(C % (4 * SsgQ<T>::value) == 0 && ldx % (4 * SsgQ<T>::value) == 0 && lddy % (4 * SsgQ<T>::value) == 0 && ssg_aligned16(x) && ssg_aligned16(dy),
+              SSG_EALIGN, "bn_bwd_reduce: C / ld must be multiples of 4 (fp32) or 8 (bf16), rows 16-byte aligned");
   return run_reduce<1, T>(x, y, dy, P, C, ldx, ldy, lddy, scale, shift, mean, invstd, act, slope, sums, nullptr, ws, (hipStream_t)stream,
                           with_count ? (double)P : 0.0);
 }
@@ -347,13 +391,16 @@ int bn_bwd_apply_impl(const T* x, const T* y, const T* dy, int64_t P, int C, int
   SSG_REQUIRE(x && dy && mean && invstd && sums && P > 0 && C > 0, SSG_EINVAL, "bn_bwd_apply: bad args");
   SSG_REQUIRE(act == SSG_ACT_NONE || (y && act != SSG_ACT_SWISH) || (scale && shift), SSG_EINVAL,
               "bn_bwd_apply: activation gradient needs y (ReLU family only) or (scale, shift)");
-  SSG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0, SSG_EALIGN, "bn_bwd_apply: alignment");
+  constexpr int G = 4 * SsgQ<T>::value;
+  SSG_REQUIRE(C % G == 0 && ldx % G == 0 && lddy % G == 0 && (!y || ldy % G == 0) && (!dx || lddx % G == 0) && (!dres || lddres % G == 0) &&
+                  ssg_aligned16(x) && ssg_aligned16(dy) && (!dx || ssg_aligned16(dx)), SSG_EALIGN,
+              "bn_bwd_apply: C/ld must be multiples of 4 (fp32) or 8 (bf16), rows 16-byte aligned");
   SSG_REQUIRE(C <= 4096, SSG_EINVAL, "bn_bwd_apply: C > 4096");
   if ((size_t)5 * C * sizeof(double) > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)bn_bwd_apply_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * C * (int)sizeof(double));
     if (e != hipSuccess) { ssg_set_error("bn_bwd_apply: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)elem_grid(P * (C / 4))), dim3(256), (size_t)5 * C * sizeof(double), (hipStream_t)stream, x, y, dy,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)elem_grid(P * (C / (4 * SsgQ<T>::value)))), dim3(256), (size_t)5 * C * sizeof(double), (hipStream_t)stream, x, y, dy,
                      (long long)P, C, ldx, ldy, lddy, mean, invstd, weight, scale, shift, sums, count, act, slope, dx, lddx, dres, lddres,
                      dweight, dbias);
   SSG_LAUNCH_CHECK();

@@ -142,7 +142,7 @@ def test_full_size_2048_image_36_patches(pkg, dev, tmp_path):
     full, patches, masks = A.get_patched_input(p, config, False)
     assert patches.shape == (36, 3, 512, 512)
     probs12 = A.infer_patches(model, patches, batch_size=12).numpy()
-    probs1g = A.infer_patches(model, patches, batch_size=1).numpy()                  # hipGraph replay per patch
+    probs1g = A.infer_patches(model, patches, batch_size=1, graph=True).numpy()      # hipGraph replay per patch
     probs1 = A.infer_patches(model, patches[:3], batch_size=1, graph=False).numpy()
     assert np.abs(probs12 - probs1g).max() < 1e-5 and np.abs(probs1 - probs1g[:3]).max() == 0.0
     # CPU oracle on two patches (eval mode, same weights)
