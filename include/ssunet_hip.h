@@ -74,7 +74,6 @@ typedef struct {
   int in_sy, in_sx, out_sy, out_sx, out_oy, out_ox;
   int ntaps; int dy[SSG_MAX_TAPS]; int dx[SSG_MAX_TAPS];   /* each in [-2, 5] */
   int act; float slope;
-  float* bnpart;            /* optional [mtiles][2][Cout] per-tile (sum, sumsq) of acc+bias; NULL = off */
 } ssg_conv_desc;
 
 int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream);
@@ -86,11 +85,9 @@ int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream);
  * 30/31/32 = conv_igemm_halo_kernel<128,128>/<256,64>/<128,64> (LDS-resident halo tile: the default for the 9 taps of
  * a 3x3 window at unit stride), 20/21/22 = conv_igemm_dma_kernel<128,128>/<256,64>/<128,64> (LDS-DMA pipeline, the default for Cin % 16 == 0
  * and Cout > 32), 12/13 = thin4 kernels on the 4x4x1 MFMA (4-channel input / Cout <= 4 with Cin % 64 == 0),
- * 10 = thin small-Cout, 11 = thin small-Cin (VALU; profiling labels). */
+ * 10 = thin small-Cout (VALU; profiling labels). */
 int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream);
 int ssg_conv2d_kernel_id(const ssg_conv_desc* d);
-/* number of M-tiles the launch above uses (rows of bnpart) */
-int ssg_conv2d_igemm_mtiles(const ssg_conv_desc* d);
 
 /* Weight packing from the reference's OIHW parameter layout [O][I][KH][KW] (the
  * state_dict layout of nn.Conv2d, archs.py:210 etc.) into the [R][Kp] operand above.

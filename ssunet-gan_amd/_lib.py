@@ -33,7 +33,6 @@ class ConvDesc(C.Structure):
         ('out_oy', C.c_int), ('out_ox', C.c_int),
         ('ntaps', C.c_int), ('dy', C.c_int * MAX_TAPS), ('dx', C.c_int * MAX_TAPS),
         ('act', C.c_int), ('slope', C.c_float),
-        ('bnpart', C.c_void_p),
     ]
 
 
@@ -59,7 +58,6 @@ _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 SIGNATURES = {
     'ssg_abi_version': [],
     'ssg_conv2d_igemm_f32': [C.POINTER(ConvDesc), _P],
-    'ssg_conv2d_igemm_mtiles': [C.POINTER(ConvDesc)],
     'ssg_conv2d_f32': [C.POINTER(ConvDesc), _P],
     'ssg_conv2d_kernel_id': [C.POINTER(ConvDesc)],
     'ssg_conv2d_wgrad_kernel_id': [C.POINTER(WgradDesc)],
@@ -144,7 +142,7 @@ _RESTYPES = {
     'ssg_sample_channel_sum_workspace_bytes': C.c_int64,
     'ssg_gemm_wgrad_bf16_workspace_bytes': C.c_int64,
 }
-_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_igemm_mtiles', 'ssg_conv2d_kernel_id', 'ssg_conv2d_wgrad_kernel_id'}
+_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_kernel_id', 'ssg_conv2d_wgrad_kernel_id'}
 
 _lib = None
 

@@ -4,7 +4,7 @@
 
 struct ConvArgs {
   const float* in1; const float* in2;
-  const float* w; const float* bias; const float* res; float* out; float* bnpart;
+  const float* w; const float* bias; const float* res; float* out;
   int C1, C2, ld1, ld2;
   int N, H, W;
   int Kp, kmode;

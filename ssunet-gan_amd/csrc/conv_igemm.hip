@@ -172,13 +172,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 
   // ---- epilogue: C/D map of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const bool want_bn = a.bnpart != nullptr;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn * WTN + j * 32 + l31;
     const bool cok = co < a.Cout;
     const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -188,7 +186,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         if (gy < a.GH && gx < a.GW) {
           const size_t pix = ((size_t)(n * a.OH + gy * a.out_sy + a.out_oy) * a.OW + gx * a.out_sx + a.out_ox);
           float v = acc[i][j][r] + bv;
-          if (want_bn) { s1 += v; s2 += v * v; }
           if (cok) {
             if (a.res) v += a.res[pix * a.ldr + co];
             if (a.act == SSG_ACT_RELU) v = v < 0.f ? 0.f : v;
@@ -198,28 +195,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             a.out[pix * a.ldo + co] = 0.f;      // keep pad channels finite (zero)
           }
         }
-      }
-    }
-    if (want_bn) {
-      // combine the two lane halves (same column), then the WAVES_M waves through LDS
-      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-      __syncthreads();                      // LDS tiles are dead now
-      float* red = lds;                     // [WAVES_M][2][BN]
-      if (half == 0) {
-        red[(wm * 2 + 0) * BN + wn * WTN + j * 32 + l31] = s1;
-        red[(wm * 2 + 1) * BN + wn * WTN + j * 32 + l31] = s2;
-      }
-      __syncthreads();
-      if (wm == 0 && half == 0 && cok) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < WAVES_M; ++k) {
-          t1 += red[(k * 2 + 0) * BN + wn * WTN + j * 32 + l31];
-          t2 += red[(k * 2 + 1) * BN + wn * WTN + j * 32 + l31];
-        }
-        float* dst = a.bnpart + (size_t)blockIdx.x * 2 * a.Cout;
-        dst[co] = t1;
-        dst[a.Cout + co] = t2;
       }
     }
   }
@@ -248,7 +223,7 @@ int pick_variant(const ssg_conv_desc* d) {
 // register-staged kernel (A/B switch for measurements).
 bool uses_dma(const ssg_conv_desc* d) {
   static const int use_dma = [] { const char* e = getenv("SSG_IGEMM_DMA"); return e ? atoi(e) : 1; }();
-  return use_dma && d->kmode == 0 && d->Cout > 32 && d->bnpart == nullptr;
+  return use_dma && d->kmode == 0 && d->Cout > 32;
 }
 
 // LDS-resident halo tile (conv_igemm_halo.hip) for the 3x3 window; SSG_IGEMM_HALO=0 switches it off (A/B)
@@ -290,7 +265,6 @@ int validate(const ssg_conv_desc* d) {
 ConvArgs to_args(const ssg_conv_desc* d) {
   ConvArgs a;
   a.in1 = d->in1; a.in2 = d->C2 ? d->in2 : d->in1; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out;
-  a.bnpart = d->bnpart;
   a.C1 = d->C1; a.C2 = d->C2; a.ld1 = d->ld1; a.ld2 = d->C2 ? d->ld2 : d->ld1;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Kp = d->Kp; a.kmode = d->kmode;
   a.ldr = d->ldr; a.Cout = d->Cout; a.ldo = d->ldo;
@@ -308,12 +282,6 @@ ConvArgs to_args(const ssg_conv_desc* d) {
 }
 
 }  // namespace
-
-extern "C" int ssg_conv2d_igemm_mtiles(const ssg_conv_desc* d) {
-  if (!d) return SSG_EINVAL;
-  const int th = (pick_variant(d) == 0) ? 8 : 16;
-  return ((d->GW + 15) / 16) * ((d->GH + th - 1) / th) * d->N;
-}
 
 extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
   int rc = validate(d);
@@ -335,7 +303,7 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
 // ssg_conv2d_kernel_id reports which kernel a descriptor maps to (for profiling labels):
 //   0..2 = conv_igemm<128,128> / <256,64> / <256,32>, 20/21/22 = conv_igemm_dma<128,128> / <256,64> / <128,64>,
 //   30/31/32 = conv_igemm_halo<128,128> / <256,64> / <128,64>,
-//   12 = thin4 (4x4x1 MFMA) 4-channel input, 13 = thin4 Cout <= 4, 10 = thin small-Cout (VALU), 11 = thin small-Cin (VALU).
+//   12 = thin4 (4x4x1 MFMA) 4-channel input, 13 = thin4 Cout <= 4, 10 = thin small-Cout (VALU).
 extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
   if (!d) return SSG_EINVAL;
   const int k4 = ssg_thin4_conv_kind(d);

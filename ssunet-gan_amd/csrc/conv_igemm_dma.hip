@@ -219,7 +219,7 @@ int launch(const ConvArgs& a0, hipStream_t st) {
 
 }  // namespace
 
-// Called by ssg_conv2d_igemm_f32 (conv_igemm.hip) for kmode 0, Cout > 32, no bnpart.
+// Called by ssg_conv2d_igemm_f32 (conv_igemm.hip) for kmode 0, Cout > 32.
 // (A <256,128> tile with 128 x 64 per wave was measured: 284 VGPRs -> one wave per SIMD, 10-50% slower.)
 // 0 = <128,128>, 1 = <256,64>, 2 = <128,64>.  Short K loops (1x1 convs, the 1/2/2/4-tap parity launches of a
 // stride-2 input gradient): a tile is mostly prologue and epilogue, and four small workgroups per CU overlap those

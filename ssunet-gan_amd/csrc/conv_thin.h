@@ -3,9 +3,6 @@
 #include "common.h"
 int ssg_thin_conv_kind(const ssg_conv_desc* d);
 int ssg_thin_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st);
-int ssg_thin_wgrad_kind(const ssg_wgrad_desc* d);
-int ssg_thin_wgrad_splits(const ssg_wgrad_desc* d, long long* pix_per_block);
-int ssg_thin_wgrad_launch(const ssg_wgrad_desc* d, int kind, hipStream_t st);
 // conv_wgrad4.hip: thin weight gradients on the 4x4x1 MFMA (kind 5 = dout thin, 6 = in thin)
 int ssg_wgrad4_kind(const ssg_wgrad_desc* d);
 int ssg_wgrad4_slices(const ssg_wgrad_desc* d, int kind, int* groups, long long* units_per_z, int* segs_per_row);

@@ -298,7 +298,7 @@ int thin4_on() {
 // mask (1 = thin-Cin, 2 = thin-Cout; default both).
 int ssg_thin4_conv_kind(const ssg_conv_desc* d) {
   if (d->C2 != 0 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox) return 0;
-  if (d->GH != d->H || d->GW != d->W || d->OH != d->H || d->OW != d->W || d->bnpart) return 0;
+  if (d->GH != d->H || d->GW != d->W || d->OH != d->H || d->OW != d->W) return 0;
   if ((long long)d->N * d->H * d->W * d->ld1 >= (1ll << 30)) return 0;          // 32-bit byte offsets
   if (((uintptr_t)d->in1 & 15) || d->ld1 % 4 || ((uintptr_t)d->w & 15) || d->Kp % 4) return 0;
   int tapidx[9];

@@ -277,10 +277,6 @@ extern "C" int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d) {
     const int nz = ssg_wgrad4_slices(d, wgrad4_kind(d), nullptr, nullptr, nullptr);
     return (int64_t)nz * d->ntaps * (d->C1 + d->C2) * d->Cout * (int64_t)sizeof(float);
   }
-  if (ssg_thin_wgrad_kind(d)) {
-    const int splits = ssg_thin_wgrad_splits(d, nullptr);
-    return (int64_t)splits * d->ntaps * (d->C1 + d->C2) * d->Cout * (int64_t)sizeof(float);
-  }
   const Plan p = make_plan(d);
   return (int64_t)p.splits * d->ntaps * (d->C1 + d->C2) * d->Cout * (int64_t)sizeof(float);
 }
@@ -291,7 +287,6 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   Plan p = make_plan(d);
   hipStream_t st = (hipStream_t)stream;
   const int w4 = wgrad4_kind(d);
-  const int thin = w4 ? 0 : ssg_thin_wgrad_kind(d);
   WgArgs a;
   a.in1 = d->in1; a.in2 = d->C2 ? d->in2 : d->in1; a.dout = d->dout; a.ws = d->ws;
   a.C1 = d->C1; a.C2 = d->C2; a.ld1 = d->ld1; a.ld2 = d->C2 ? d->ld2 : d->ld1;
@@ -306,10 +301,6 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   if (w4) {
     p.splits = ssg_wgrad4_slices(d, w4, nullptr, nullptr, nullptr);
     rc = ssg_wgrad4_launch(d, w4, st);
-    if (rc != SSG_OK) return rc;
-  } else if (thin) {
-    p.splits = ssg_thin_wgrad_splits(d, nullptr);
-    rc = ssg_thin_wgrad_launch(d, thin, st);
     if (rc != SSG_OK) return rc;
   } else {
     dim3 grid((unsigned)p.mt, (unsigned)p.nt, (unsigned)p.splits);
@@ -364,12 +355,10 @@ extern "C" int ssg_pack_weights_f32(const float* w_oihw, int O, int I, int KH, i
   return SSG_OK;
 }
 
-// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 30/31 = wgrad_halo<32,128>/<64,64>, 13/14 = thin (VALU), 15/16 = wgrad4 (4x4x1 MFMA)
+// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 30/31 = wgrad_halo<32,128>/<64,64>, 15/16 = wgrad4 (4x4x1 MFMA)
 extern "C" int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d) {
   if (!d) return SSG_EINVAL;
   if (wgrad4_kind(d)) return 10 + wgrad4_kind(d);
-  const int k = ssg_thin_wgrad_kind(d);
-  if (k) return 10 + k;
   if (make_plan(d).halo) return 30 + make_plan(d).variant;
   const int v = make_plan(d).variant;
   return v + (wgrad_uses_dma(v) ? 20 : 0);

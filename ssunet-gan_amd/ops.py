@@ -175,12 +175,11 @@ PROFILE_SHAPES = False      # debug: append the launch geometry to the label
 _CONV_LABELS = {0: 'conv_igemm_kernel<128,128>', 1: 'conv_igemm_kernel<256,64>', 2: 'conv_igemm_kernel<256,32>',
                 20: 'conv_igemm_dma_kernel<128,128>', 21: 'conv_igemm_dma_kernel<256,64>', 22: 'conv_igemm_dma_kernel<128,64>',
                 30: 'conv_igemm_halo_kernel<128,128>', 31: 'conv_igemm_halo_kernel<256,64>', 32: 'conv_igemm_halo_kernel<128,64>',
-                10: 'thin_small_cout_kernel', 11: 'thin_small_cin_kernel',
+                10: 'thin_small_cout_kernel',
                 12: 'thin4_cin_kernel', 13: 'thin4_cout_kernel'}
 _WGRAD_LABELS = {0: 'wgrad_kernel<128,128>', 1: 'wgrad_kernel<128,64>', 2: 'wgrad_kernel<128,32>',
                  20: 'wgrad_dma_kernel<128,128>', 21: 'wgrad_dma_kernel<128,64>',
                  30: 'wgrad_halo_kernel<32,128>', 31: 'wgrad_halo_kernel<64,64>',
-                 13: 'thin_wgrad_small_cout_kernel', 14: 'thin_wgrad_small_cin_kernel',
                  15: 'wgrad4_kernel<thin_cout>', 16: 'wgrad4_kernel<thin_cin>'}
 
 
@@ -202,7 +201,7 @@ class _Timed(object):
 
 
 def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps, n, h, w, gh, gw, oh, ow,
-                 in_s, out_s, out_oy, out_ox, out, bnpart=None):
+                 in_s, out_s, out_oy, out_ox, out):
     d = ConvDesc()
     d.in1 = x1.data_ptr(); d.C1 = pad4(x1.shape[1]); d.ld1 = _ld(x1)
     if x2 is not None:
@@ -223,7 +222,6 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     d.out_oy, d.out_ox = out_oy, out_ox
     _fill_taps(d, taps)
     d.act = act; d.slope = slope
-    d.bnpart = bnpart.data_ptr() if bnpart is not None else None
     cred = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
     label = None
     if PROFILE is not None:

@@ -420,12 +420,12 @@ def test_layout_roundtrip_and_errors(pkg, dev):
         pkg.ops.conv2d(torch.randn(1, 4, 4, 4).to(dev), torch.randn(4, 8, 3, 3).to(dev), None, 1, 1)
 
 
-def test_all_thin_kernels_enabled_subprocess():
-    """The thin VALU kernels that are off by default (SSG_THIN_MASK, conv_thin.hip) stay exact:
-    rerun the conv cases in a subprocess with all four enabled."""
+def test_thin_valu_kernel_switched_off_subprocess():
+    """SSG_THIN_MASK=0 routes the small-Cout case of the one remaining VALU thin kernel (conv_thin.hip, T1) back to the
+    MFMA paths: both routes stay exact (the conv cases are rerun in a subprocess with the switch off)."""
     import os, subprocess, sys
     from conftest import ROOT
-    env = dict(os.environ, SSG_THIN_MASK='15')
+    env = dict(os.environ, SSG_THIN_MASK='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_ops_gpu.py'), '-m', 'gpu', '-q', '-x',
                         '-k', 'conv2d_fwd_bwd or concat', '-p', 'no:cacheprovider'], env=env, cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
