@@ -193,8 +193,7 @@ def test_literal_reference_train_body_on_hip_modules(pkg, dev):
     perceptual_loss.backward()
     if grad_clip is not None:
         S.srgan_utils.clip_gradient(optimizer_g, grad_clip)
-    optimizer_g.step()
-    S.ops.bump_weight_epoch()            # stock optimizer.step() wrote the weights: INTEGRATION.md 1 (the one added line)
+    optimizer_g.step()                   # stock in-place update: tensor version counters move, packed-weight caches follow
     hr_discriminated = discriminator(target)
     sr_discriminated = discriminator(generator_output.detach())
     adversarial_loss = adversarial_loss_criterion(sr_discriminated, torch.zeros_like(sr_discriminated)) + \
@@ -204,7 +203,6 @@ def test_literal_reference_train_body_on_hip_modules(pkg, dev):
     if grad_clip is not None:
         S.srgan_utils.clip_gradient(optimizer_d, grad_clip)
     optimizer_d.step()
-    S.ops.bump_weight_epoch()
     lit = dict(loss=float(loss), iou=float(iou), dice=float(dice), adv=float(adversarial_loss),
                g=[p.detach().clone() for p in generator.parameters()], d=[p.detach().clone() for p in discriminator.parameters()])
     # ---- the fused step ----
