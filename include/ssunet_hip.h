@@ -235,6 +235,10 @@ int ssg_bn_bwd_apply_f32(const float* x, const float* y, const float* dy, int64_
  * and NaN wins, as ATen's CPU max_pool2d does. */
 int ssg_maxpool2x2_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, uint8_t* idx, void* stream);
 int ssg_maxpool2x2_bwd_f32(const float* dy, int lddy, const uint8_t* idx, int N, int H, int W, int C, float* dx, int lddx, void* stream);
+/* dx = res + maxpool backward(dy): the gradient of an encoder output that feeds both the pool and a skip connection
+ * (archs.py:628-667) in one pass; res is laid out like dx. */
+int ssg_maxpool2x2_bwd_add_f32(const float* dy, int lddy, const uint8_t* idx, const float* res, int ldr, int N, int H, int W, int C,
+                               float* dx, int lddx, void* stream);
 int ssg_maxunpool2x2_fwd_f32(const float* x, int ldx, const uint8_t* idx, int N, int OH, int OW, int C, float* y, int ldy, void* stream);
 int ssg_maxunpool2x2_bwd_f32(const float* dy, int lddy, const uint8_t* idx, int N, int OH, int OW, int C, float* dx, int lddx, void* stream);
 int ssg_upsample2x_bilinear_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, void* stream);

@@ -74,6 +74,7 @@ SIGNATURES = {
     'ssg_bn_bwd_apply_f32': [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _D, _I, _F, _P, _I, _P, _I, _P, _P, _P],
     'ssg_maxpool2x2_fwd_f32': [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     'ssg_maxpool2x2_bwd_f32': [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P],
+    'ssg_maxpool2x2_bwd_add_f32': [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     'ssg_maxunpool2x2_fwd_f32': [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P],
     'ssg_maxunpool2x2_bwd_f32': [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P],
     'ssg_upsample2x_bilinear_fwd_f32': [_P, _I, _I, _I, _I, _I, _P, _I, _P],

@@ -42,8 +42,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 
 // scatter src[n,oy,ox,c] to the argmax position of its 2x2 window in dst (zeros elsewhere):
 // = max-pool backward and = max-unpool forward.
+// `res` (optional, laid out like dst) is added: the gradient of a tensor that feeds BOTH a max-pool and a skip connection
+// (archs.py:628-667: every encoder output) is formed in this pass instead of by a separate 3-tensor add.
 __global__ __launch_bounds__(256) void scatter2x2_kernel(const float* __restrict__ src, int lds_, const uint8_t* __restrict__ idx,
-                                                         int N, int OH, int OW, int C, float* __restrict__ dst, int ldd) {
+                                                         int N, int OH, int OW, int C, float* __restrict__ dst, int ldd,
+                                                         const float* __restrict__ res, int ldr) {
   const int CQ = C / 4, H = OH * 2, W = OW * 2;
   const long long total = (long long)N * OH * OW * CQ;
   GRID_STRIDE(i, total) {
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(256) void scatter2x2_kernel(const float* __restrict
       f32x4 w;
 #pragma unroll
       for (int e = 0; e < 4; ++e) w[e] = (((pk >> (8 * e)) & 255u) == (uint32_t)k) ? v[e] : 0.f;
+      if (res) w += *(const f32x4*)(res + (((size_t)(n * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1)) * ldr + 4 * cq));
       *(f32x4*)(b + ((size_t)(k >> 1) * W + (k & 1)) * ldd) = w;
     }
   }
@@ -266,7 +270,16 @@ extern "C" int ssg_maxpool2x2_bwd_f32(const float* dy, int lddy, const uint8_t* 
   SSG_REQUIRE(dy && dx && idx && N > 0 && H % 2 == 0 && W % 2 == 0, SSG_EINVAL, "maxpool_bwd: needs even H, W");
   REQ_Q(C, "maxpool_bwd: C %% 4");
   const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(scatter2x2_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, idx, N, H / 2, W / 2, C, dx, lddx);
+  hipLaunchKernelGGL(scatter2x2_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, idx, N, H / 2, W / 2, C, dx, lddx, (const float*)nullptr, 0);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+extern "C" int ssg_maxpool2x2_bwd_add_f32(const float* dy, int lddy, const uint8_t* idx, const float* res, int ldr, int N, int H, int W, int C,
+                                         float* dx, int lddx, void* stream) {
+  SSG_REQUIRE(dy && dx && idx && res && N > 0 && H % 2 == 0 && W % 2 == 0 && ldr % 4 == 0, SSG_EINVAL, "maxpool_bwd_add: bad args");
+  REQ_Q(C, "maxpool_bwd_add: C %% 4");
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(scatter2x2_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, idx, N, H / 2, W / 2, C, dx, lddx, res, ldr);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -274,7 +287,7 @@ extern "C" int ssg_maxunpool2x2_fwd_f32(const float* x, int ldx, const uint8_t* 
   SSG_REQUIRE(x && y && idx && N > 0 && OH % 2 == 0 && OW % 2 == 0, SSG_EINVAL, "maxunpool: bad args");
   REQ_Q(C, "maxunpool: C %% 4");
   const long long total = (long long)N * (OH / 2) * (OW / 2) * (C / 4);
-  hipLaunchKernelGGL(scatter2x2_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, idx, N, OH / 2, OW / 2, C, y, ldy);
+  hipLaunchKernelGGL(scatter2x2_kernel, dim3(elem_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, idx, N, OH / 2, OW / 2, C, y, ldy, (const float*)nullptr, 0);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

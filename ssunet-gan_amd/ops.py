@@ -16,7 +16,7 @@ import torch.distributed as dist
 from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvDesc, WgradDesc, call, ptr, stream_ptr
 
-__all__ = ['conv2d', 'batch_norm_act', 'max_pool2x2', 'max_unpool2x2', 'upsample2x_bilinear', 'upsample2x_nearest',
+__all__ = ['conv2d', 'batch_norm_act', 'max_pool2x2', 'max_pool2x2_skip', 'max_unpool2x2', 'upsample2x_bilinear', 'upsample2x_nearest',
            'spade_modulate', 'adaptive_avgpool_flat', 'linear', 'seg_loss', 'bce_with_logits_const', 'nan_to_zero_',
            'to_nhwc', 'new_nhwc', 'bump_weight_epoch', 'dwconv2d', 'swish', 'sigmoid', 'gaussian', 'mul', 'global_avgpool',
            'channel_scale', 'spectral_norm_weight']
@@ -652,6 +652,50 @@ def max_pool2x2(x):
     """nn.MaxPool2d(2, 2, return_indices=True): returns (y, idx) with idx the 1-byte window argmax."""
     _lib.require_gpu(x)
     return _MaxPool.apply(x)
+
+
+class _MaxPoolSkip(torch.autograd.Function):
+    """max_pool2x2 of a tensor that ALSO feeds a skip connection: returns (y, idx, x_skip) with x_skip = x.  One autograd node
+    receives both gradients and forms dx = d_skip + pool_backward(dy) in the pool-backward pass, so autograd never launches
+    its own 3-tensor add for the encoder outputs (archs.py:628-667: up to 1 GB each at 16 x 512^2)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        if c % 4 or h % 2 or w % 2:
+            raise ValueError('max_pool2x2: needs C %% 4 == 0 and even H, W (got %s)' % (tuple(x.shape),))
+        oh, ow = h // 2, w // 2
+        y = new_nhwc(n, c, oh, ow, x.device)
+        idx = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device)
+        call('ssg_maxpool2x2_fwd_f32', ptr(x), n, h, w, c, _ld(x), ptr(y), _ld(y), ptr(idx), stream_ptr())
+        ctx.save_for_backward(idx)
+        ctx.hw = (h, w)
+        ctx.mark_non_differentiable(idx)
+        return y, idx, x
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy, _, dskip):
+        (idx,) = ctx.saved_tensors
+        h, w = ctx.hw
+        if dy is None:
+            return dskip
+        dy = to_nhwc(dy)
+        n, c, oh, ow = dy.shape
+        dx = new_nhwc(n, c, h, w, dy.device)
+        if dskip is None:
+            call('ssg_maxpool2x2_bwd_f32', ptr(dy), _ld(dy), ptr(idx), n, h, w, c, ptr(dx), _ld(dx), stream_ptr())
+        else:
+            dskip = to_nhwc(dskip)
+            call('ssg_maxpool2x2_bwd_add_f32', ptr(dy), _ld(dy), ptr(idx), ptr(dskip), _ld(dskip), n, h, w, c, ptr(dx), _ld(dx), stream_ptr())
+        return dx
+
+
+def max_pool2x2_skip(x):
+    """(y, idx, x_skip): max_pool2x2(x) plus x handed back for a skip connection; use x_skip (not x) downstream."""
+    _lib.require_gpu(x)
+    return _MaxPoolSkip.apply(x)
 
 
 class _MaxUnpool(torch.autograd.Function):

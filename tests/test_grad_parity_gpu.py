@@ -45,6 +45,7 @@ class _Capture(object):
     def __enter__(self):
         ops, blocks = self.pkg.ops, self.pkg.blocks
         bn0, conv0, pool0, lin0 = ops._bn_fwd_impl, ops._conv_fwd_impl, ops.max_pool2x2, ops.linear
+        pools0 = ops.max_pool2x2_skip
         cap = self
 
         def bn(x, weight, bias, rm, rv, res, eps, momentum, act, slope, var_mode, group):
@@ -64,6 +65,11 @@ class _Capture(object):
             cap.items.append(idx.detach().permute(0, 3, 1, 2).long().cpu().contiguous())
             return y, idx
 
+        def pool_skip(x):
+            y, idx, xs = pools0(x)
+            cap.items.append(idx.detach().permute(0, 3, 1, 2).long().cpu().contiguous())
+            return y, idx, xs
+
         def lin(x, weight, bias=None, act=0, slope=0.0):
             cap._mute = True
             try:
@@ -74,9 +80,9 @@ class _Capture(object):
                 cap.items.append(cap._nchw_mask(y))
             return y
 
-        self._saved = [(ops, '_bn_fwd_impl', bn0), (ops, '_conv_fwd_impl', conv0), (ops, 'max_pool2x2', pool0), (ops, 'linear', lin0),
+        self._saved = [(ops, '_bn_fwd_impl', bn0), (ops, '_conv_fwd_impl', conv0), (ops, 'max_pool2x2', pool0), (ops, 'max_pool2x2_skip', pools0), (ops, 'linear', lin0),
                        (blocks, '_bn_fwd_impl', blocks._bn_fwd_impl), (blocks, '_conv_fwd_impl', blocks._conv_fwd_impl)]
-        ops._bn_fwd_impl = bn; ops._conv_fwd_impl = conv; ops.max_pool2x2 = pool; ops.linear = lin
+        ops._bn_fwd_impl = bn; ops._conv_fwd_impl = conv; ops.max_pool2x2 = pool; ops.max_pool2x2_skip = pool_skip; ops.linear = lin
         blocks._bn_fwd_impl = bn; blocks._conv_fwd_impl = conv
         return self
 
