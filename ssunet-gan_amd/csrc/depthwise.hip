@@ -117,13 +117,25 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial_kernel(const DwArgs<T> a
     for (int e = 0; e < 4; ++e) dst[e] = tot[e];
   }
 }
-__global__ void dw_wgrad_final_kernel(const double* __restrict__ part, int parts, int KK, int C, float* __restrict__ dw) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // over KK*C, idx = t*C + c
-  if (idx >= KK * C) return;
+// Second stages: 8 outputs x 32 part-lanes per 256-thread block.  Lane k of an output adds partial rows k, k+32, ... in row
+// order, then the 32 lane sums are folded by a fixed xor tree: a fixed summation order (bitwise reproducible) with 1/32 of
+// the serial chain of one thread per output (the one-thread version took 19-30 us per launch, all of it dependent loads).
+__device__ __forceinline__ double fold32(double v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+  return v;
+}
+__global__ __launch_bounds__(256) void dw_wgrad_final_kernel(const double* __restrict__ part, int parts, int KK, int C, float* __restrict__ dw) {
+  const int lane = threadIdx.x & 31;
+  const int idx = blockIdx.x * 8 + (threadIdx.x >> 5);           // over KK*C, idx = t*C + c
   double s = 0;
-  for (int b = 0; b < parts; ++b) s += part[(size_t)b * KK * C + idx];
-  const int t = idx / C, c = idx - t * C;
-  dw[(size_t)c * KK + t] = (float)s;
+  if (idx < KK * C)
+    for (int b = lane; b < parts; b += 32) s += part[(size_t)b * KK * C + idx];
+  s = fold32(s);
+  if (lane == 0 && idx < KK * C) {
+    const int t = idx / C, c = idx - t * C;
+    dw[(size_t)c * KK + t] = (float)s;
+  }
 }
 
 // ---------------------------------------------------------------- stride-1 depthwise, register tiled
@@ -364,12 +376,15 @@ __global__ __launch_bounds__(256) void sample_colsum_kernel(const T* __restrict_
 }
 __global__ __launch_bounds__(256) void sample_colsum_final_kernel(const double* __restrict__ part, int slices, int NC, int C, float scale,
                                                                   float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= NC) return;
-  const int n = i / C, c = i - n * C;
+  const int lane = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
   double t = 0;
-  for (int z = 0; z < slices; ++z) t += part[((size_t)n * slices + z) * C + c];
-  out[i] = (float)(t * scale);
+  if (i < NC) {
+    const int n = i / C, c = i - n * C;
+    for (int z = lane; z < slices; z += 32) t += part[((size_t)n * slices + z) * C + c];
+  }
+  t = fold32(t);
+  if (lane == 0 && i < NC) out[i] = (float)(t * scale);
 }
 int sample_colsum_slices(int N, long long S, int C) {
   const long long blocks = (long long)((C / 4 + DW_TQ - 1) / DW_TQ) * N;
@@ -457,7 +472,7 @@ int dwconv_wgrad_impl(const T* in, int N, int H, int W, int C, int ld, const T* 
   hipLaunchKernelGGL(dw_wgrad_partial_kernel<T>, dim3((unsigned)parts, (unsigned)((C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)(KH * KW)), dim3(256), 0, st,
                      a, rpp, (double*)ws);
   SSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dw_wgrad_final_kernel, dim3((unsigned)((KH * KW * C + 127) / 128)), dim3(128), 0, st, (const double*)ws, (int)parts, KH * KW, C, dw);
+  hipLaunchKernelGGL(dw_wgrad_final_kernel, dim3((unsigned)((KH * KW * C + 7) / 8)), dim3(256), 0, st, (const double*)ws, (int)parts, KH * KW, C, dw);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -539,7 +554,7 @@ int sample_channel_sum_impl(const T* a, int lda, const T* b, int ldb, int N, int
   hipLaunchKernelGGL(sample_colsum_kernel<T>, dim3((unsigned)((C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)N, (unsigned)z), dim3(256), 0, (hipStream_t)stream,
                      a, lda, b, ldb, (long long)S, C, rps, (double*)ws);
   SSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sample_colsum_final_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const double*)ws, z, N * C, C,
+  hipLaunchKernelGGL(sample_colsum_final_kernel, dim3((unsigned)((N * C + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (const double*)ws, z, N * C, C,
                      scale, out);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
