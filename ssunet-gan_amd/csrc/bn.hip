@@ -52,7 +52,8 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
   long long p1 = p0 + rows_per_part; if (p1 > P) p1 = P;
   // fp64 accumulators: var = E[x^2] - mean^2 cancels catastrophically in fp32 for channels whose
   // variance is far below mean^2 (deep layers with few pixels); x*x is exact in fp64.
-  double s1[V], s2[V];
+  typedef typename SsgAcc<T>::type acc_t;
+  acc_t s1[V], s2[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) { s1[e] = 0; s2[e] = 0; }
   float mu[V], is[V], sc[V], sh[V];
@@ -73,12 +74,12 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const double v = (double)xq[q][e]; s1[4 * q + e] += v; s2[4 * q + e] += v * v; }
+          for (int e = 0; e < 4; ++e) { const acc_t v = (acc_t)xq[q][e]; s1[4 * q + e] += v; s2[4 * q + e] += v * v; }
       } else if (MODE == 2) {
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) s1[4 * q + e] += (double)xq[q][e];
+          for (int e = 0; e < 4; ++e) s1[4 * q + e] += (acc_t)xq[q][e];
       } else {
         f32x4 gq[Q], yq[Q];
         ldq(dy + p * lddy + V * cg, gq);
@@ -100,15 +101,15 @@ __global__ __launch_bounds__(RED_BLOCK) void col_reduce_kernel(
               const float yv = use_y ? yq[q][e] : xv * sc[k] + sh[k];
               if (!(yv > 0.f)) g *= (act == SSG_ACT_RELU ? 0.f : slope);
             }
-            const double xh = ((double)xv - (double)mu[k]) * (double)is[k];
-            s1[k] += (double)g; s2[k] += (double)g * xh;
+            const acc_t xh = ((acc_t)xv - (acc_t)mu[k]) * (acc_t)is[k];
+            s1[k] += (acc_t)g; s2[k] += (acc_t)g * xh;
           }
         }
       }
     }
   }
 #pragma unroll
-  for (int e = 0; e < V; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+  for (int e = 0; e < V; ++e) { red[0][tid][e] = (double)s1[e]; red[1][tid][e] = (double)s2[e]; }
   __syncthreads();
   if (pr == 0 && cok) {
     double a1[V], a2[V];
@@ -304,8 +305,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int c = cb + e;
-          const double xh = ((double)xv[e] - k_mean[c]) * k_is[c];
-          o[e] = (float)(k_ws[c] * ((double)g[e] - k_m1[c] - xh * k_m2[c]));
+          typedef typename SsgAcc<T>::type acc_t;          // fp64 for fp32 tensors, fp32 for bf16 (common.h)
+          const acc_t xh = ((acc_t)xv[e] - (acc_t)k_mean[c]) * (acc_t)k_is[c];
+          o[e] = (float)((acc_t)k_ws[c] * ((acc_t)g[e] - (acc_t)k_m1[c] - xh * (acc_t)k_m2[c]));
         }
         oq[q] = o;
       }

@@ -22,6 +22,12 @@ __device__ __forceinline__ void st4(ssg_bf16* p, f32x4 v) { *(ssg_bf16x4*)p = __
 // 16 bytes per lane for either type: SSG_Q<T> channel quads per memory access (1 for fp32, 2 for bf16).  The element-wise
 // kernels that are latency-bound at 8 B per lane (one load in flight per thread) use these: a bf16 thread then moves as many
 // bytes per instruction as an fp32 one and works on 8 channels.  Needs C % (4 * SSG_Q<T>) == 0 and 16-byte aligned rows.
+// Per-thread accumulation type of the reducing kernels: fp64 for fp32 tensors (ATen's CPU kernels accumulate float tensors in
+// double, and var = E[x^2] - mean^2 cancels: DESIGN.md 3.2); fp32 for bf16 tensors, whose own rounding (2^-9) is four orders
+// above fp32 accumulation error over the <= few hundred terms a thread sums -- the cross-thread / cross-block stages stay
+// fp64 for both.  (fp64 VALU runs at half rate: with half the bytes per element the bf16 instantiations were VALU-bound.)
+template <typename T> struct SsgAcc { typedef double type; };
+template <> struct SsgAcc<__bf16> { typedef float type; };
 typedef __bf16 ssg_bf16x8 __attribute__((ext_vector_type(8)));
 template <typename T> struct SsgQ { static constexpr int value = 1; };
 template <> struct SsgQ<ssg_bf16> { static constexpr int value = 2; };
@@ -62,16 +68,20 @@ void ssg_set_error(const char* fmt, ...);
 static inline bool ssg_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline int64_t ssg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// sigmoid on the hardware transcendentals (v_exp_f32 + v_rcp_f32, ~1 ulp each; |relative error| < 1e-6 for |x| < 10):
+// the library expf + IEEE division made the swish-fused batch-norm kernels VALU-bound (2.5 TB/s on 0.9-GB tensors).
+__device__ __forceinline__ float ssg_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 __device__ __forceinline__ float ssg_act(float v, int act, float slope) {
   // NaN-propagating forms, as ATen's relu (clamp_min) and leaky_relu
   if (act == SSG_ACT_RELU) return v < 0.f ? 0.f : v;
   if (act == SSG_ACT_LRELU) return v > 0.f ? v : v * slope;
-  if (act == SSG_ACT_SWISH) return v / (1.f + expf(-v));                 // x * sigmoid(x) (efficientnet_pytorch/utils.py:37-48)
+  if (act == SSG_ACT_SWISH) return v * ssg_sigmoid_fast(v);              // x * sigmoid(x) (efficientnet_pytorch/utils.py:37-48)
   return v;
 }
 
 // d act(z) / dz for the activations whose derivative is a function of the pre-activation z
 __device__ __forceinline__ float ssg_swish_grad(float z) {
-  const float s = 1.f / (1.f + expf(-z));
+  const float s = ssg_sigmoid_fast(z);
   return s * (1.f + z * (1.f - s));                                     // utils.py:45-48
 }

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial_kernel(const DwArgs<T> a
   const long long P = (long long)a.N * a.OH * a.OW;
   const long long p0 = (long long)blockIdx.x * rows_per_part;
   long long p1 = p0 + rows_per_part; if (p1 > P) p1 = P;
-  double s[4] = {0, 0, 0, 0};
+  typedef typename SsgAcc<T>::type acc_t;
+  acc_t s[4] = {0, 0, 0, 0};
   if (cq < CQ) {
     for (long long p = p0 + pr; p < p1; p += PR) {
       const int ox = (int)(p % a.OW); const long long r = p / a.OW;
@@ -100,12 +101,12 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial_kernel(const DwArgs<T> a
         const f32x4 g = ld4(a.dout + (size_t)p * a.ldo + 4 * cq);
         const f32x4 v = ld4(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.ld + 4 * cq);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] += (double)g[e] * (double)v[e];
+        for (int e = 0; e < 4; ++e) s[e] += (acc_t)g[e] * (acc_t)v[e];
       }
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) red[tid][e] = s[e];
+  for (int e = 0; e < 4; ++e) red[tid][e] = (double)s[e];
   __syncthreads();
   if (pr == 0 && cq < CQ) {
     double tot[4] = {0, 0, 0, 0};
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs<T> a, lon
   const long long P = (long long)a.N * a.OH * a.OW;
   const long long p0 = (long long)blockIdx.x * rows_per_part;
   long long p1 = p0 + rows_per_part; if (p1 > P) p1 = P;
-  double s[KW][4];
+  typedef typename SsgAcc<T>::type acc_t;
+  acc_t s[KW][4];
 #pragma unroll
   for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs<T> a, lon
         if ((unsigned)ix < (unsigned)a.W) {
           const f32x4 v = ld4(row + (size_t)ix * a.ld);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) s[kx][e] += (double)g[e] * (double)v[e];
+          for (int e = 0; e < 4; ++e) s[kx][e] += (acc_t)g[e] * (acc_t)v[e];
         }
       }
     }
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs<T> a, lon
   for (int kx = 0; kx < KW; ++kx) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[tid][e] = s[kx][e];
+    for (int e = 0; e < 4; ++e) red[tid][e] = (double)s[kx][e];
     __syncthreads();
     if (pr == 0 && cq < CQ) {
       double tot[4] = {0, 0, 0, 0};
@@ -353,17 +355,18 @@ __global__ __launch_bounds__(256) void sample_colsum_kernel(const T* __restrict_
   const int CQ = C / 4, cq = blockIdx.x * DW_TQ + tq, n = blockIdx.y;
   const long long p0 = (long long)blockIdx.z * rows_per_slice;
   long long p1 = p0 + rows_per_slice; if (p1 > S) p1 = S;
-  double s[4] = {0, 0, 0, 0};
+  typedef typename SsgAcc<T>::type acc_t;
+  acc_t s[4] = {0, 0, 0, 0};
   if (cq < CQ)
     for (long long p = p0 + pr; p < p1; p += PR) {
       const size_t row = (size_t)n * S + p;
       f32x4 v = ld4(a + row * lda + 4 * cq);
       if (b) v = v * ld4(b + row * ldb + 4 * cq);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
+      for (int e = 0; e < 4; ++e) s[e] += (acc_t)v[e];
     }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) red[tid][e] = s[e];
+  for (int e = 0; e < 4; ++e) red[tid][e] = (double)s[e];
   __syncthreads();
   if (pr == 0 && cq < CQ) {
 #pragma unroll
