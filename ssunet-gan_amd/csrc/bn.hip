@@ -262,13 +262,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       if (dbias) dbias[c] = (float)sums[c];
     }
   }
-  // per-channel fp64 constants once per block (the fp64 divisions are not repeated per element)
-  extern __shared__ double kc[];                 // [4][C]: mean, invstd, w*invstd, then m1 | m2 packed below
-  double* k_mean = kc; double* k_is = kc + C; double* k_ws = kc + 2 * C; double* k_m1 = kc + 3 * C; double* k_m2 = kc + 4 * C;
+  // per-channel constants once per block, evaluated in fp64 (the divisions are not repeated per element) and kept in the
+  // accumulation type of the tensor family: fp64 for fp32 tensors, fp32 for bf16 (common.h)
+  typedef typename SsgAcc<T>::type acc_t;
+  extern __shared__ double kc_raw[];
+  acc_t* kc = (acc_t*)kc_raw;                    // [5][C]: mean, invstd, w*invstd, m1, m2
+  acc_t* k_mean = kc; acc_t* k_is = kc + C; acc_t* k_ws = kc + 2 * C; acc_t* k_m1 = kc + 3 * C; acc_t* k_m2 = kc + 4 * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     const double is = (double)invstd[c];
-    k_mean[c] = (double)mean[c]; k_is[c] = is; k_ws[c] = (weight ? (double)weight[c] : 1.0) * is;
-    k_m1[c] = sums[c] / count; k_m2[c] = sums[C + c] / count;
+    k_mean[c] = (acc_t)mean[c]; k_is[c] = (acc_t)is; k_ws[c] = (acc_t)((weight ? (double)weight[c] : 1.0) * is);
+    k_m1[c] = (acc_t)(sums[c] / count); k_m2[c] = (acc_t)(sums[C + c] / count);
   }
   __syncthreads();
   constexpr int Q = SsgQ<T>::value;
@@ -305,9 +308,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int c = cb + e;
-          typedef typename SsgAcc<T>::type acc_t;          // fp64 for fp32 tensors, fp32 for bf16 (common.h)
-          const acc_t xh = ((acc_t)xv[e] - (acc_t)k_mean[c]) * (acc_t)k_is[c];
-          o[e] = (float)((acc_t)k_ws[c] * ((acc_t)g[e] - (acc_t)k_m1[c] - xh * (acc_t)k_m2[c]));
+          const acc_t xh = ((acc_t)xv[e] - k_mean[c]) * k_is[c];
+          o[e] = (float)(k_ws[c] * ((acc_t)g[e] - k_m1[c] - xh * k_m2[c]));
         }
         oq[q] = o;
       }

@@ -154,7 +154,7 @@ def test_full_size_2048_image_36_patches(pkg, dev, tmp_path):
     err = np.abs(ref - probs12[[0, 17]])
     # 1.5 M pooled windows per patch: a handful of near-tie argmax choices may differ between the two implementations (they feed
     # max-unpool), so the bound is on robust statistics, as in the 256^2 step test
-    assert np.median(err) < 2e-6 and (err > 5e-5).mean() < 1e-4 and err.max() < 1e-2, 'vs CPU oracle: max %.3e median %.3e' % (err.max(), np.median(err))
+    assert np.median(err) < 2e-6 and (err > 5e-5).mean() < 1e-3 and err.max() < 1e-2, 'vs CPU oracle: max %.3e median %.3e' % (err.max(), np.median(err))
     all_mask, gt_mask = A.segmentation_inference_full(model, full, patches, masks, config, False, batch_size=12)
     assert len(all_mask) == 3 and all_mask[1].shape == (2048, 2048) and all_mask[1].dtype == np.uint8
     assert set(np.unique(all_mask[1])) <= {0, 255} and gt_mask is all_mask
