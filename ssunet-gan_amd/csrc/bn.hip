@@ -148,9 +148,9 @@ __global__ __launch_bounds__(RED_BLOCK) void modulate_bwd_sums_kernel(
       const f32x4 g = *(const f32x4*)(gb + p * ldgb + 4 * cq);
       const f32x4 d = *(const f32x4*)(dy + p * lddy + 4 * cq);
       const f32x4 dg = d * xv;
-      *(f32x4*)(dx + p * lddx + 4 * cq) = d * (1.f + g);
-      *(f32x4*)(dgb + p * lddgb + 4 * cq) = dg;
-      *(f32x4*)(dgb + p * lddgb + C + 4 * cq) = d;
+      st4(dx + p * lddx + 4 * cq, d * (1.f + g));
+      st4(dgb + p * lddgb + 4 * cq, dg);
+      st4(dgb + p * lddgb + C + 4 * cq, d);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s1[e] += (double)dg[e]; s2[e] += (double)d[e]; }
     }

@@ -16,8 +16,16 @@ typedef __bf16 ssg_bf16;
 typedef __bf16 ssg_bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 __device__ __forceinline__ f32x4 ld4(const ssg_bf16* p) { return __builtin_convertvector(*(const ssg_bf16x4*)p, f32x4); }
+#ifndef SSG_NT_STORES
+#define SSG_NT_STORES 0      // 1: streaming stores of the element-wise kernels are non-temporal (A/B build switch)
+#endif
+#if SSG_NT_STORES
+__device__ __forceinline__ void st4(float* p, f32x4 v) { __builtin_nontemporal_store(v, (f32x4*)p); }
+__device__ __forceinline__ void st4(ssg_bf16* p, f32x4 v) { __builtin_nontemporal_store(__builtin_convertvector(v, ssg_bf16x4), (ssg_bf16x4*)p); }
+#else
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
 __device__ __forceinline__ void st4(ssg_bf16* p, f32x4 v) { *(ssg_bf16x4*)p = __builtin_convertvector(v, ssg_bf16x4); }
+#endif
 
 // 16 bytes per lane for either type: SSG_Q<T> channel quads per memory access (1 for fp32, 2 for bf16).  The element-wise
 // kernels that are latency-bound at 8 B per lane (one load in flight per thread) use these: a bf16 thread then moves as many
@@ -37,12 +45,16 @@ __device__ __forceinline__ void ldq(const ssg_bf16* p, f32x4 (&v)[2]) {
   v[0] = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
   v[1] = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
 }
-__device__ __forceinline__ void stq(float* p, const f32x4 (&v)[1]) { *(f32x4*)p = v[0]; }
+__device__ __forceinline__ void stq(float* p, const f32x4 (&v)[1]) { st4(p, v[0]); }
 __device__ __forceinline__ void stq(ssg_bf16* p, const f32x4 (&v)[2]) {
   ssg_bf16x8 r;
 #pragma unroll
   for (int e = 0; e < 4; ++e) { r[e] = (ssg_bf16)v[0][e]; r[4 + e] = (ssg_bf16)v[1][e]; }
+#if SSG_NT_STORES
+  __builtin_nontemporal_store(r, (ssg_bf16x8*)p);
+#else
   *(ssg_bf16x8*)p = r;
+#endif
 }
 
 void ssg_set_error(const char* fmt, ...);

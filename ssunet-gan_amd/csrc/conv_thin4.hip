@@ -14,6 +14,10 @@
 // Same descriptor contract as ssg_conv2d_igemm_f32 (bias, residual, activation, pad lanes written as 0).
 #include "common.h"
 #include "conv_thin.h"
+#ifndef SSG_T4_EXP
+#define SSG_T4_EXP 0      // 1 = no MFMAs, 2 = no output stores: ablation builds of thin4_cin (tools/micro_thin_exp.py), never shipped
+#endif
+#include <stdlib.h>
 
 namespace {
 
@@ -23,6 +27,7 @@ struct T4Args {
   int tapidx[9];             // tap index at window position (dy+1)*3 + (dx+1), or -1
   int act; float slope;
   int groups, waves_per_group, total_units, strips, ybands;
+  int nt_store;              // thin-Cin: non-temporal output stores (output larger than the caches)
 };
 
 constexpr int RH_CIN = 16;       // rows per work unit (thin-Cin): a 4-pixel-wide strip marched downwards
@@ -44,9 +49,19 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
 // neighbours), the load of row y+R+1 is in flight while row y is multiplied.
 
 // ------------------------------------------------------------------ thin-Cin: C == 4
-template <int KS>
+// PF = rows of input in flight ahead of the row being multiplied.  vmcnt retires in order and counts stores: with PF = 1 the
+// wait for the one prefetched row also waits for the 1-KiB output store issued just before it, i.e. every row pays a full
+// store round trip (the waves sat in s_waitcnt 55-60 % of their cycles, 2.5 TB/s).  With PF rows in flight the counted wait
+// leaves the PF-1 youngest row loads AND the stores between them outstanding.  12 VGPRs per extra row (KS = 3): PF = 3 keeps
+// the kernel at 3 waves per SIMD (164 <= 168 registers).
+// HAS_RES: the residual is a compile-time property of the kernel.  As a runtime `if (a.res)` around a plain global load,
+// hipcc branched around the load and put `s_waitcnt vmcnt(0)` in front of its use IN EVERY ROW, taken or not: that drained
+// the just-issued output store and every prefetched row each iteration (the kernel ran at 2.3 TB/s whatever PF was).  The
+// residual now comes through the buffer descriptor path (OOB offset instead of a branch), one row ahead, so the compiler
+// emits counted waits only.
+template <int KS, int PF, bool HAS_RES>
 __global__ __launch_bounds__(256) void thin4_cin_kernel(const T4Args a) {
-  constexpr int R = KS / 2, NT = KS * KS, RING = KS + 1;
+  constexpr int R = KS / 2, NT = KS * KS, RING = KS + PF;
   const int lane = threadIdx.x & 63, j = lane & 3, b = lane >> 2;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int cg = wid % a.groups, wg = wid / a.groups;
@@ -54,6 +69,8 @@ __global__ __launch_bounds__(256) void thin4_cin_kernel(const T4Args a) {
   const unsigned npix = (unsigned)(a.N * a.H * a.W);
   const auto in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)(npix * (unsigned)a.ld * 4u), 0x00020000);
   const unsigned ldb = (unsigned)a.ld * 4u;
+  const auto res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_RES ? a.res : a.in), 0,
+                                                        (int)(npix * (unsigned)(HAS_RES ? a.ldr : a.ld) * 4u), 0x00020000);
 
   // A operand: this lane's output channel, all taps x 4 channels (kmode 1: k = t*4 + c)
   const int co = cg * 64 + lane;
@@ -98,20 +115,37 @@ __global__ __launch_bounds__(256) void thin4_cin_kernel(const T4Args a) {
     };
     f32x4 v[RING][KS];
 #pragma unroll
-    for (int q = 0; q < KS; ++q) load_row(v[q], y0 - R + q);
+    for (int q = 0; q < KS + PF - 1; ++q) load_row(v[q], y0 - R + q);
+    // residual of output row yy (this lane's pixel column, its 4 channels): one row ahead, ring-indexed like v
+    f32x4 rvr[HAS_RES ? RING : 1];
+    auto load_res = [&](int yy) -> f32x4 {
+      const bool ok = x < a.W && st_ok && yy < y1;
+      return ldbuf4(res_rs, ok ? ((unsigned)((n * a.H + yy) * a.W + x) * (unsigned)a.ldr + (unsigned)cb) * 4u : OOB);
+    };
+    if (HAS_RES) rvr[0] = load_res(y0);
     for (int y = y0; y < y1; y += RING) {
 #pragma unroll
       for (int r = 0; r < RING; ++r) {
         if (y + r < y1) {
           // The previous row's result is stored here, a whole MFMA phase before the next s_waitcnt has to
           // cover it (gfx9 counts stores in vmcnt: a store issued right before the wait exposes its latency).
-          if (pend_ptr) *(f32x4*)pend_ptr = pend;
-          load_row(v[(r + KS) % RING], y + r - R + KS);
+#if SSG_T4_EXP == 2
+          if (pend_ptr && pend[0] == 123.456f) *(f32x4*)pend_ptr = pend;          // ablation: no output stores
+#else
+          // outputs far larger than the caches (the 1-GB gamma / beta buffers of the 512^2 level) are stored non-temporally:
+          // 0.474 -> 0.402 ms on 16 x 512^2, 4 -> 64 (tools/micro_thin_exp.py)
+          if (pend_ptr) { if (a.nt_store) __builtin_nontemporal_store(pend, (f32x4*)pend_ptr); else *(f32x4*)pend_ptr = pend; }
+#endif
+          // row (y + r) + R + PF goes into the slot of row (y + r) - R - 1, whose last reader was the previous iteration
+          load_row(v[(r + KS + PF - 1) % RING], y + r - R + KS + PF - 1);
           const size_t pix = (size_t)(n * a.H + y + r) * a.W + x;
           f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-          if (a.res && x < a.W && st_ok) rv = *(const f32x4*)(a.res + pix * a.ldr + cb);
+          if (HAS_RES) { rvr[(r + 1) % RING] = load_res(y + r + 1); rv = rvr[r]; }
           // two accumulator chains (even / odd k) keep dependent MFMAs apart
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#if SSG_T4_EXP == 1
+          acc0 = v[r % RING][0] + v[(r + KS - 1) % RING][KS - 1];                  // ablation: no MFMAs (rows stay live)
+#else
 #pragma unroll
           for (int q = 0; q < KS; ++q)
 #pragma unroll
@@ -121,6 +155,7 @@ __global__ __launch_bounds__(256) void thin4_cin_kernel(const T4Args a) {
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[q * KS + e][c], v[(r + q) % RING][e][c], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[q * KS + e][c + 1], v[(r + q) % RING][e][c + 1], acc1, 0, 0, 0);
               }
+#endif
           const f32x4 t = acc0 + acc1 + bv + rv * cmask;
 #pragma unroll
           for (int i = 0; i < 4; ++i) pend[i] = (t[i] < 0.f ? (is_relu ? 0.f : t[i] * neg_slope) : t[i]) * cmask[i];
@@ -304,7 +339,7 @@ int ssg_thin4_conv_kind(const ssg_conv_desc* d) {
   int tapidx[9];
   if (!window_taps(d, tapidx)) return 0;
   if ((thin4_on() & 1) && d->C1 == 4 && d->kmode == 1 && d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) &&
-      (!d->res || (d->ldr % 4 == 0 && !((uintptr_t)d->res & 15)))) return 3;
+      (!d->res || (d->ldr % 4 == 0 && !((uintptr_t)d->res & 15) && (long long)d->N * d->H * d->W * d->ldr < (1ll << 30)))) return 3;
   if ((thin4_on() & 2) && d->Cout <= 8 && d->C1 >= 64 && d->C1 % 64 == 0 && d->ldo % 2 == 0 && !((uintptr_t)d->out & 7)) return 4;
   return 0;
 }
@@ -316,6 +351,7 @@ int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
   a.ldr = d->ldr; a.Cout = d->Cout; a.ldo = d->ldo; a.ntaps = d->ntaps;
   a.act = d->act; a.slope = d->slope;
   window_taps(d, a.tapidx);
+  a.nt_store = (long long)d->N * d->H * d->W * d->ldo * 4 >= (256ll << 20);
   bool ks1 = true;
   for (int p = 0; p < 9; ++p) if (p != 4 && a.tapidx[p] >= 0) ks1 = false;
   const int rh = kind == 3 ? RH_CIN : RH_COUT;
@@ -328,8 +364,14 @@ int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
   a.waves_per_group = wpg;
   const dim3 grid((unsigned)((wpg * a.groups + 3) / 4)), block(256);
   if (kind == 3) {
-    if (ks1) hipLaunchKernelGGL(thin4_cin_kernel<1>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(thin4_cin_kernel<3>, grid, block, 0, st, a);
+    static const int pf = [] { const char* e = getenv("SSG_THIN4_PF"); return e ? atoi(e) : 2; }();     // rows in flight (A/B switch)
+    if (d->res) {
+      if (ks1) hipLaunchKernelGGL((thin4_cin_kernel<1, 1, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((thin4_cin_kernel<3, 1, true>), grid, block, 0, st, a);
+    } else if (ks1) hipLaunchKernelGGL((thin4_cin_kernel<1, 2, false>), grid, block, 0, st, a);
+    else if (pf <= 1) hipLaunchKernelGGL((thin4_cin_kernel<3, 1, false>), grid, block, 0, st, a);
+    else if (pf == 2) hipLaunchKernelGGL((thin4_cin_kernel<3, 2, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((thin4_cin_kernel<3, 4, false>), grid, block, 0, st, a);
   } else {
     if (d->Cout <= 4) {
       if (ks1) hipLaunchKernelGGL((thin4_cout_kernel<1, 1>), grid, block, 0, st, a);

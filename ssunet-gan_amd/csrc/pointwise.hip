@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void modulate_fwd_kernel(const float* __restri
     const long long p = i / CQ; const int cq = (int)(i - p * CQ);
     const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
     const f32x4 g = *(const f32x4*)(gb + p * ldgb + 4 * cq), b = *(const f32x4*)(gb + p * ldgb + C + 4 * cq);
-    *(f32x4*)(y + p * ldy + 4 * cq) = xv * (1.f + g) + b;
+    st4(y + p * ldy + 4 * cq, xv * (1.f + g) + b);
   }
 }
 __global__ __launch_bounds__(256) void modulate_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gb, int ldgb,
@@ -33,9 +33,9 @@ __global__ __launch_bounds__(256) void modulate_bwd_kernel(const float* __restri
     const f32x4 xv = *(const f32x4*)(x + p * ldx + 4 * cq);
     const f32x4 g = *(const f32x4*)(gb + p * ldgb + 4 * cq);
     const f32x4 d = *(const f32x4*)(dy + p * lddy + 4 * cq);
-    *(f32x4*)(dx + p * lddx + 4 * cq) = d * (1.f + g);
-    *(f32x4*)(dgb + p * lddgb + 4 * cq) = d * xv;
-    *(f32x4*)(dgb + p * lddgb + C + 4 * cq) = d;
+    st4(dx + p * lddx + 4 * cq, d * (1.f + g));
+    st4(dgb + p * lddgb + 4 * cq, d * xv);
+    st4(dgb + p * lddgb + C + 4 * cq, d);
   }
 }
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dy, int lddy,
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     f32x4 d = *(const f32x4*)(dy + p * lddy + 4 * cq);
 #pragma unroll
     for (int e = 0; e < 4; ++e) if (!(yv[e] > 0.f)) d[e] *= (act == SSG_ACT_RELU ? 0.f : (act == SSG_ACT_LRELU ? slope : 1.f));
-    *(f32x4*)(dx + p * lddx + 4 * cq) = d;
+    st4(dx + p * lddx + 4 * cq, d);
   }
 }
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ o) {
