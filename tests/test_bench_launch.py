@@ -43,7 +43,7 @@ def test_pmc_traffic_rows_cover_the_mfma_kernels_of_the_tracked_trace():
     import bench
     src, table = bench.pmc_traffic_table()
     assert src and table, 'no profiles/rNN_*pmc_hbm_traffic_per_kernel.csv'
-    traces = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_*kernel_stats_bench_bs16_512.csv'))     # traces of bench.py itself)
+    traces = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_*kernel_stats_bench_bs16_512.csv')))     # traces of bench.py itself
     assert traces
     assert os.path.basename(traces[-1])[:3] == os.path.basename(src)[:3], 'PMC summary %s is older than the kernel trace %s' % (src, traces[-1])
     names = [bench._norm_symbol(r['Name']) for r in csv.DictReader(open(traces[-1]))]
