@@ -118,6 +118,7 @@ def _pack(weight, transpose):
     return hit, kp
 
 
+PROFILE_SHAPES = False  # append the GEMM shape to the label
 PROFILE = None          # tools/bench_b4.py: list receiving (label, flops, bytes, start event, end event) per GEMM launch
 
 
@@ -143,7 +144,7 @@ class _Conv1x1(torch.autograd.Function):
         wp, kp = _pack(weight, 0)
         y = new_bf16(n, o, h, w, x.device)
         p = n * h * w
-        _timed('gemm_bf16_kernel fwd', 2.0 * p * c * o, 2.0 * p * (c + o) + 2.0 * c * o,
+        _timed('gemm_bf16_kernel fwd' + (' P%d K%d N%d' % (p, c, o) if PROFILE_SHAPES else ''), 2.0 * p * c * o, 2.0 * p * (c + o) + 2.0 * c * o,
                lambda: call('ssg_gemm_bf16', ptr(x), p, c, ldx, ptr(wp), kp, o, None, 0, ptr(y), o, stream_ptr()))
         ctx.save_for_backward(x, weight)
         return y
@@ -160,13 +161,13 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt, kpt = _pack(weight, 1)
             dx = new_bf16(n, c, h, w, x.device)
-            _timed('gemm_bf16_kernel dgrad', 2.0 * p * c * o, 2.0 * p * (c + o) + 2.0 * c * o,
+            _timed('gemm_bf16_kernel dgrad' + (' P%d K%d N%d' % (p, o, c) if PROFILE_SHAPES else ''), 2.0 * p * c * o, 2.0 * p * (c + o) + 2.0 * c * o,
                    lambda: call('ssg_gemm_bf16', ptr(dy), p, o, o, ptr(wt), kpt, c, None, 0, ptr(dx), c, stream_ptr()))
         if ctx.needs_input_grad[1]:
             nbytes = call('ssg_gemm_wgrad_bf16_workspace_bytes', p, o, c)
             ws = ops._ws(nbytes, x.device)
             dw = torch.empty((o, c, 1, 1), dtype=torch.float32, device=x.device)
-            _timed('gemm_wgrad_bf16_kernel', 2.0 * p * c * o, 2.0 * p * (c + o) + 4.0 * c * o,
+            _timed('gemm_wgrad_bf16_kernel' + (' P%d M%d N%d' % (p, o, c) if PROFILE_SHAPES else ''), 2.0 * p * c * o, 2.0 * p * (c + o) + 4.0 * c * o,
                    lambda: call('ssg_gemm_wgrad_bf16', ptr(dy), o, ptr(x), c, p, o, c, ptr(dw), ptr(ws), nbytes, stream_ptr()))
         return dx, dw
 

@@ -295,12 +295,17 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
   }
 }
 
-int wg_splits(long long P, int tiles) {
+int wg_splits(long long P, int M, int N) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   const long long nk = (P + 31) / 32;
-  long long s = 512 / (tiles > 0 ? tiles : 1);
+  // ~512 workgroups when the slabs are large; up to ~2048 when a slab is a few KB (thin layers over 10^5..10^6 pixels:
+  // with 512 the 24 x 24 gradient over 1 M pixels ran on 256 workgroups at 0.6 TB/s)
+  const long long slab_bytes = (long long)M * N * 4;
+  long long target = slab_bytes <= (64 << 10) ? 2048 : (slab_bytes <= (512 << 10) ? 1024 : 512);
+  long long s = target / (tiles > 0 ? tiles : 1);
   if (s > nk / 8) s = nk / 8;                 // at least 8 K-steps per split
   if (s < 1) s = 1;
-  if (s > 256) s = 256;
+  if (s > 2048) s = 2048;
   return (int)s;
 }
 
@@ -325,8 +330,7 @@ extern "C" int ssg_gemm_bf16(const void* x, int64_t P, int K, int ldx, const voi
 }
 
 extern "C" int64_t ssg_gemm_wgrad_bf16_workspace_bytes(int64_t P, int M, int N) {
-  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  return (int64_t)wg_splits(P, tiles) * M * N * (int64_t)sizeof(float);
+  return (int64_t)wg_splits(P, M, N) * M * N * (int64_t)sizeof(float);
 }
 
 extern "C" int ssg_gemm_wgrad_bf16(const void* dy, int ldd, const void* x, int ldx, int64_t P, int M, int N, float* dw, void* ws,
@@ -338,7 +342,7 @@ extern "C" int ssg_gemm_wgrad_bf16(const void* dy, int ldd, const void* x, int l
   a.dy = (const unsigned short*)dy; a.x = (const unsigned short*)x; a.slabs = (float*)ws;
   a.P = P; a.M = M; a.N = N; a.ldd = ldd; a.ldx = ldx;
   a.tiles_m = (M + 127) / 128; a.tiles_n = (N + 127) / 128;
-  a.splits = wg_splits(P, a.tiles_m * a.tiles_n);
+  a.splits = wg_splits(P, M, N);
   SSG_REQUIRE(ws_bytes >= (int64_t)a.splits * M * N * (int64_t)sizeof(float), SSG_EINVAL, "gemm_wgrad_bf16: workspace too small");
   const long long nk = (P + 31) / 32;
   a.steps_per_split = (nk + a.splits - 1) / a.splits;

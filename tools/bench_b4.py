@@ -93,12 +93,21 @@ def main():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--shapes', action='store_true', help='per-shape table of the bf16 GEMM launches on stderr')
     ap.add_argument('--only', choices=['both', 'bf16'], default='both', help="'bf16': skip the fp32 leg (for a clean kernel trace)")
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     flop_img = 3 * 2 * GMAC_FWD_B4_1024 * 1e9 * (args.size / 1024.0) ** 2
     dt32 = run(torch.float32, args, dev, False)[0] if args.only == 'both' else float('nan')
+    S.bf16.PROFILE_SHAPES = args.shapes
     dt16e, prof = run(torch.bfloat16, args, dev, True)
+    if args.shapes:
+        tab = {}
+        for label, flops, nbytes, e0, e1 in prof or []:
+            a = tab.setdefault(label, [0.0, 0.0, 0.0, 0]); a[0] += flops; a[1] += nbytes; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += 1
+        for k, v in sorted(tab.items(), key=lambda kv: -kv[1][2]):
+            print('%-52s x%-3d %8.1f us  %6.2f TB/s %7.1f TF' % (k, v[3] // args.steps, v[2] / v[3] * 1e6, v[1] / v[2] / 1e12, v[0] / v[2] / 1e12), file=sys.stderr)
+        prof = [(l.split(' P')[0], f, b, e0, e1) for l, f, b, e0, e1 in prof]
     try:
         dt16, graph_ok = run_graph(torch.bfloat16, args, dev)
         graph_note = 'hipGraph replay of the captured fwd+bwd' if graph_ok else 'graph replay produced non-finite gradients'
