@@ -273,12 +273,25 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf16_kernel(const WgArgsH a) {
   }
 }
 
+// Ordered slab reduce.  One thread per output when there are few slabs; with many (thin layers: up to 2048 slabs of a few KB)
+// 32 lanes share an output: lane k adds slabs k, k+32, ... in order, then the 32 lane sums are folded by a fixed xor tree --
+// a fixed summation order either way (bitwise reproducible), 1/32 of the serial chain.
 __global__ __launch_bounds__(256) void gemm_wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, long long MN, float* __restrict__ dw) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= MN) return;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * MN + i];      // fixed order: bitwise reproducible
+  for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * MN + i];
   dw[i] = s;
+}
+__global__ __launch_bounds__(256) void gemm_wgrad_reduce32_kernel(const float* __restrict__ slabs, int splits, long long MN, float* __restrict__ dw) {
+  const int lane = threadIdx.x & 31;
+  const long long i = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  float s = 0.f;
+  if (i < MN)
+    for (int k = lane; k < splits; k += 32) s += slabs[(size_t)k * MN + i];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+  if (lane == 0 && i < MN) dw[i] = s;
 }
 
 // w fp32 [O][I] -> bf16 [rows_pad][Kp], rows = O (transpose 0) or I (transpose 1), zero padded
@@ -350,7 +363,10 @@ extern "C" int ssg_gemm_wgrad_bf16(const void* dy, int ldd, const void* x, int l
   hipLaunchKernelGGL(gemm_wgrad_bf16_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(256), W_STAGES * W_STAGE_BYTES, st, a);
   SSG_LAUNCH_CHECK();
   const long long MN = (long long)M * N;
-  hipLaunchKernelGGL(gemm_wgrad_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, (const float*)ws, a.splits, MN, dw);
+  if (a.splits >= 64 && MN <= (1 << 18))
+    hipLaunchKernelGGL(gemm_wgrad_reduce32_kernel, dim3((unsigned)((MN + 7) / 8)), dim3(256), 0, st, (const float*)ws, a.splits, MN, dw);
+  else
+    hipLaunchKernelGGL(gemm_wgrad_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, (const float*)ws, a.splits, MN, dw);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
