@@ -98,6 +98,11 @@ int ssg_conv2d_kernel_id(const ssg_conv_desc* d);
 int ssg_pack_weights_f32(const float* w_oihw, int O, int I, int KH, int KW,
                          int transpose, int ntaps, const int* ky, const int* kx,
                          int kmode, int Cred_pad, int Kp, float* out, void* stream);
+/* The same with every weight multiplied by 1 / *sigma (device scalar): a spectrally normalised conv (spectral_norm.py:86-88)
+ * packs `weight_orig` with its sigma, so W / sigma is never materialised in OIHW form. */
+int ssg_pack_weights_scaled_f32(const float* w_oihw, int O, int I, int KH, int KW,
+                                int transpose, int ntaps, const int* ky, const int* kx,
+                                int kmode, int Cred_pad, int Kp, const float* sigma, float* out, void* stream);
 
 /* Weight gradient (replaces conv2d's weight-grad at the same call sites).
  *   dw[co, c, ky[t], kx[t]] = sum_{n,gy,gx} dout[n,gy,gx,co] * in[n, gy*in_sy+dy[t], gx*in_sx+dx[t], c]
@@ -345,7 +350,7 @@ int ssg_sample_channel_sum_f32(const float* a, int lda, const float* b, int ldb,
                                void* ws, void* stream);
 int ssg_broadcast_rows_f32(const float* s, int N, int64_t S, int C, float scale, float* y, int ldy, void* stream);
 /* Spectral norm (spectral_norm.py:38-88): power iteration on W [rows][cols] with in-place u [rows],
- * v [cols]; W_out = W / sigma, sigma = u.(W v).  Backward treats u, v as constants:
+ * v [cols]; W_out = W / sigma (W_out may be NULL: sigma only), sigma = u.(W v).  Backward treats u, v as constants:
  * dW = dWsn/sigma - (sum(dWsn.W)/sigma^2) u v^T. */
 int64_t ssg_spectral_norm_workspace_bytes(int rows, int cols);
 int ssg_spectral_norm_fwd_f32(const float* W, int rows, int cols, float* u, float* v, int n_power_iterations, double eps,

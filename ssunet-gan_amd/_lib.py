@@ -62,6 +62,7 @@ SIGNATURES = {
     'ssg_conv2d_kernel_id': [C.POINTER(ConvDesc)],
     'ssg_conv2d_wgrad_kernel_id': [C.POINTER(WgradDesc)],
     'ssg_pack_weights_f32': [_P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _P, _P],
+    'ssg_pack_weights_scaled_f32': [_P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _P, _P, _P],
     'ssg_conv2d_wgrad_workspace_bytes': [C.POINTER(WgradDesc)],
     'ssg_conv2d_wgrad_f32': [C.POINTER(WgradDesc), _P],
     'ssg_nchw_to_nhwc_f32': [_P, _I, _I, _I, _I, _P, _I, _P],
@@ -134,6 +135,7 @@ SIGNATURES['ssg_add_bf16'] = [_P, _I, _P, _I, _L, _I, _P, _I, _P]
 SIGNATURES['ssg_convert_f32_to_bf16'] = [_P, _I, _L, _I, _P, _I, _P]
 SIGNATURES['ssg_convert_bf16_to_f32'] = [_P, _I, _L, _I, _P, _I, _P]
 _RESTYPES = {
+    'ssg_pack_weights_scaled_f32': [_P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _P, _P, _P],
     'ssg_conv2d_wgrad_workspace_bytes': C.c_int64,
     'ssg_bn_workspace_bytes': C.c_int64,
     'ssg_seg_loss_workspace_bytes': C.c_int64,

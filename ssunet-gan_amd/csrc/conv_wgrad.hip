@@ -246,7 +246,8 @@ int validate(const ssg_wgrad_desc* d) {
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int O, int I, int KH, int KW,
                                                            int transpose, int ntaps, unsigned long long kpos_bits,
-                                                           int kmode, int Cred_pad, int Kp, int R, float* __restrict__ out) {
+                                                           int kmode, int Cred_pad, int Kp, int R, float* __restrict__ out,
+                                                           const float* __restrict__ sigma) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)R * Kp) return;
   const int r = (int)(idx / Kp), k = (int)(idx - (long long)r * Kp);
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     const int ky = kb & 7, kx = kb >> 3;
     const int o = transpose ? c : r, i = transpose ? r : c;
     v = w[(((size_t)o * I + i) * KH + ky) * KW + kx];
+    if (sigma) v *= 1.f / *sigma;            // spectral norm: W / sigma never exists in OIHW form, the scale rides the pack
   }
   out[idx] = v;
 }
@@ -332,9 +334,17 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   return SSG_OK;
 }
 
+extern "C" int ssg_pack_weights_scaled_f32(const float* w_oihw, int O, int I, int KH, int KW, int transpose, int ntaps,
+                                           const int* ky, const int* kx, int kmode, int Cred_pad, int Kp, const float* sigma, float* out,
+                                           void* stream);
 extern "C" int ssg_pack_weights_f32(const float* w_oihw, int O, int I, int KH, int KW, int transpose, int ntaps,
                                     const int* ky, const int* kx, int kmode, int Cred_pad, int Kp, float* out,
                                     void* stream) {
+  return ssg_pack_weights_scaled_f32(w_oihw, O, I, KH, KW, transpose, ntaps, ky, kx, kmode, Cred_pad, Kp, nullptr, out, stream);
+}
+extern "C" int ssg_pack_weights_scaled_f32(const float* w_oihw, int O, int I, int KH, int KW, int transpose, int ntaps,
+                                           const int* ky, const int* kx, int kmode, int Cred_pad, int Kp, const float* sigma, float* out,
+                                           void* stream) {
   SSG_REQUIRE(w_oihw && out && ky && kx, SSG_EINVAL, "pack: null pointer");
   SSG_REQUIRE(ntaps >= 1 && ntaps <= SSG_MAX_TAPS && KH <= 8 && KW <= 8, SSG_EINVAL, "pack: taps");
   SSG_REQUIRE(Kp % 16 == 0 && Cred_pad % 4 == 0, SSG_EINVAL, "pack: Kp/Cred_pad");
@@ -350,7 +360,7 @@ extern "C" int ssg_pack_weights_f32(const float* w_oihw, int O, int I, int KH, i
   const int R = transpose ? I : O;
   const long long tot = (long long)R * Kp;
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)ssg_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream,
-                     w_oihw, O, I, KH, KW, transpose, ntaps, bits, kmode, Cred_pad, Kp, R, out);
+                     w_oihw, O, I, KH, KW, transpose, ntaps, bits, kmode, Cred_pad, Kp, R, out, sigma);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -96,7 +96,7 @@ extern "C" int64_t ssg_spectral_norm_workspace_bytes(int rows, int cols) {
 
 extern "C" int ssg_spectral_norm_fwd_f32(const float* W, int rows, int cols, float* u, float* v, int n_power_iterations, double eps,
                                          float* W_out, float* sigma, void* ws, void* stream) {
-  SSG_REQUIRE(W && u && v && W_out && sigma && ws && rows > 0 && cols > 0 && n_power_iterations >= 0, SSG_EINVAL, "spectral_norm: bad args");
+  SSG_REQUIRE(W && u && v && sigma && ws && rows > 0 && cols > 0 && n_power_iterations >= 0, SSG_EINVAL, "spectral_norm: bad args");
   hipStream_t st = (hipStream_t)stream;
   double* t = (double*)ws;          // [cols]
   double* s = t + cols;             // [rows]
@@ -110,9 +110,11 @@ extern "C" int ssg_spectral_norm_fwd_f32(const float* W, int rows, int cols, flo
     hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)rows), dim3(256), 0, st, W, rows, cols, v, s);
     hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, u, s, rows, sigma);
   }
-  const long long n = (long long)rows * cols;
-  long long g = (n + 255) / 256; if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)g), dim3(256), 0, st, W, n, sigma, W_out);
+  if (W_out) {                       // W_out == NULL: sigma only (the conv applies 1/sigma while packing W: ssg_pack_weights_scaled_f32)
+    const long long n = (long long)rows * cols;
+    long long g = (n + 255) / 256; if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)g), dim3(256), 0, st, W, n, sigma, W_out);
+  }
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from . import archs, ops
 from ._lib import ACT_LRELU, ACT_NONE
+from .spectral_norm import SpectralNorm
 
 
 def remove_prefix(state_dict, prefix):
@@ -42,16 +43,27 @@ class ConvolutionalBlock(nn.Module):
         conv = self.conv_block[0]
         # The conv runs through ops.conv2d on conv.weight, not through nn.Conv2d.__call__: forward pre-hooks registered on the
         # conv module (spectral_norm re-parametrises `weight` in one: spectral_norm.py:99-101) are honoured here.
+        sn = None
         for hook in conv._forward_pre_hooks.values():
-            hook(conv, (input,))
+            if isinstance(hook, SpectralNorm) and hook.name == 'weight' and hook.dim == 0 and conv.weight_orig.is_cuda:
+                sn = hook            # handled inside the conv below: W / sigma is never materialised (ops.conv2d_sn)
+            else:
+                hook(conv, (input,))
         if self._act not in (None, 'leakyrelu'):
             raise NotImplementedError('ConvolutionalBlock activation %r has no HIP path (only the discriminator\'s '
                                       'LeakyReLU flavour is on the hot path)' % self._act)
         act = ACT_LRELU if self._act == 'leakyrelu' else ACT_NONE
         slope = self.conv_block[-1].negative_slope if act == ACT_LRELU else 0.0
+        if sn is not None:
+            def run(a, sl):
+                return ops.conv2d_sn(input, conv.weight_orig, conv.weight_u, conv.weight_v, conv.bias, conv.stride[0], conv.padding[0],
+                                     act=a, slope=sl, n_power_iterations=sn.n_power_iterations if conv.training else 0, eps=sn.eps)
+        else:
+            def run(a, sl):
+                return ops.conv2d(input, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act=a, slope=sl)
         if not self._bn:
-            return ops.conv2d(input, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act=act, slope=slope)
-        y = ops.conv2d(input, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+            return run(act, slope)
+        y = run(ACT_NONE, 0.0)
         bn = self.conv_block[1]
         return ops.batch_norm_act(y, bn, act=act, slope=slope, group=getattr(bn, '_ssg_sync_group', None))
 

@@ -19,7 +19,7 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvDesc, WgradDesc, call, ptr,
 __all__ = ['conv2d', 'batch_norm_act', 'max_pool2x2', 'max_pool2x2_skip', 'max_unpool2x2', 'upsample2x_bilinear', 'upsample2x_nearest',
            'spade_modulate', 'adaptive_avgpool_flat', 'linear', 'seg_loss', 'bce_with_logits_const', 'nan_to_zero_',
            'to_nhwc', 'new_nhwc', 'bump_weight_epoch', 'dwconv2d', 'swish', 'sigmoid', 'gaussian', 'mul', 'global_avgpool',
-           'channel_scale', 'spectral_norm_weight']
+           'channel_scale', 'spectral_norm_weight', 'conv2d_sn']
 
 
 def pad4(c):
@@ -129,13 +129,20 @@ def _taps_fwd(kh, kw, pad):
     return [(ky, kx, ky - pt, kx - pl) for ky in range(kh) for kx in range(kw)]
 
 
-def _pack(weight, transpose, taps, cred_pad, c1_for_mode):
-    """Pack an OIHW weight for the given tap list; returns (tensor[R, Kp], Kp, kmode)."""
+def _pack(weight, transpose, taps, cred_pad, c1_for_mode, sigma=None):
+    """Pack an OIHW weight for the given tap list; returns (tensor[R, Kp], Kp, kmode).  `sigma` (device scalar): pack
+    weight / sigma instead (spectral norm; sigma changes every training forward, so this pack is not cached)."""
     o, i, kh, kw = weight.shape
     nt = len(taps)
     kmode = 0 if (cred_pad % 16 == 0 and c1_for_mode % 16 == 0) else 1
     kp = nt * cred_pad if kmode == 0 else (nt * cred_pad + 15) // 16 * 16
     rows = i if transpose else o
+    if sigma is not None:
+        out = torch.empty((rows, kp), device=weight.device, dtype=torch.float32)
+        ky = (C.c_int * nt)(*[t[0] for t in taps]); kx = (C.c_int * nt)(*[t[1] for t in taps])
+        wc = weight.detach().contiguous()
+        call('ssg_pack_weights_scaled_f32', ptr(wc), o, i, kh, kw, int(transpose), nt, ky, kx, kmode, cred_pad, kp, ptr(sigma), ptr(out), stream_ptr())
+        return out, kp, kmode
     # The cache lives ON the parameter object (never keyed by address alone: a freed tensor's
     # address can be reused by another weight).  Entries are valid for one (storage address,
     # autograd version, optimizer epoch) of that parameter.
@@ -241,7 +248,7 @@ def _out_hw(h, w, kh, kw, s, pad):
     return (h + pt + pb - kh) // s + 1, (w + pl + pr - kw) // s + 1
 
 
-def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=None):
+def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=None, wscale=None):
     o, i, kh, kw = weight.shape
     n, c1, h, w = x1.shape
     c2 = x2.shape[1] if x2 is not None else 0
@@ -251,7 +258,7 @@ def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=
         raise ValueError('conv: input channels %d+%d != weight in-channels %d' % (c1, c2, i))
     cred_pad = pad4(c1) + pad4(c2)
     taps = _taps_fwd(kh, kw, pad)
-    wpk, kp, kmode = _pack(weight, 0, taps, cred_pad, pad4(c1))
+    wpk, kp, kmode = _pack(weight, 0, taps, cred_pad, pad4(c1), sigma=wscale)
     oh, ow = _out_hw(h, w, kh, kw, stride, pad)
     if out is None:
         out = new_nhwc(n, o, oh, ow, x1.device)
@@ -259,7 +266,7 @@ def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=
     return out
 
 
-def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None):
+def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None, wscale=None):
     """Input gradient for input channels [c_lo, c_hi) -> NHWC tensor [N, c_hi-c_lo, h, w].
     `res` (same shape) is added in the epilogue: gradient accumulation without an extra pass."""
     o, i, kh, kw = weight.shape
@@ -269,7 +276,7 @@ def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None):
     dx = new_nhwc(n, c_hi - c_lo, h, w, dy.device)
     if stride == 1:
         taps = [(ky, kx, pt - ky, pl - kx) for ky in range(kh) for kx in range(kw)]
-        wpk, kp, kmode = _pack(weight, 1, taps, cred_pad, cred_pad)
+        wpk, kp, kmode = _pack(weight, 1, taps, cred_pad, cred_pad, sigma=wscale)
         _conv_launch(dy, None, wpk, kp, kmode, c_lo, c_hi - c_lo, None, res, ACT_NONE, 0.0, taps, n, oh, ow, h, w, h, w, 1, 1, 0, 0, dx)
         return dx
     if res is not None:
@@ -287,7 +294,7 @@ def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None):
         gh, gw = (h - py + s - 1) // s, (w - px + s - 1) // s
         if not taps or gh <= 0 or gw <= 0:
             continue
-        wpk, kp, kmode = _pack(weight, 1, taps, cred_pad, cred_pad)
+        wpk, kp, kmode = _pack(weight, 1, taps, cred_pad, cred_pad, sigma=wscale)
         _conv_launch(dy, None, wpk, kp, kmode, c_lo, c_hi - c_lo, None, None, ACT_NONE, 0.0, taps, n, oh, ow, gh, gw, h, w, 1, s, py, px, dx)
     return dx
 
@@ -1169,6 +1176,57 @@ class _SpectralNormWeight(torch.autograd.Function):
         ws = _ws(call('ssg_spectral_norm_workspace_bytes', rows, cols), wm.device)
         call('ssg_spectral_norm_bwd_f32', ptr(dwsn), ptr(wm), rows, cols, ptr(u), ptr(v), ptr(sigma), ptr(dw), ptr(ws), stream_ptr())
         return dw, None, None, None, None
+
+
+class _Conv2dSN(torch.autograd.Function):
+    """conv2d(x, weight_orig / sigma) (+bias, +activation) with the spectral norm INSIDE the conv: one in-place power iteration
+    on (u, v) -> sigma (spectral_norm.py:73-88), then weight_orig is packed with 1/sigma for the forward and the input
+    gradient.  W / sigma is never written out, nothing of the weight is cached across forwards (sigma moves every training
+    forward), and the weight gradient is mapped back through dW = dWsn/sigma - (sum(dWsn . W)/sigma^2) u v^T."""
+
+    @staticmethod
+    def forward(ctx, x, weight_orig, u, v, bias, stride, pad, act, slope, n_iter, eps):
+        x = to_nhwc(x)
+        wm = weight_orig.contiguous()
+        rows = wm.shape[0]
+        cols = wm.numel() // rows
+        sigma = torch.empty((), dtype=torch.float32, device=wm.device)
+        ws = _ws(call('ssg_spectral_norm_workspace_bytes', rows, cols), wm.device)
+        call('ssg_spectral_norm_fwd_f32', ptr(wm), rows, cols, ptr(u), ptr(v), n_iter, float(eps), None, ptr(sigma), ptr(ws), stream_ptr())
+        y = _conv_fwd_impl(x, None, wm, bias, stride, pad, act, slope, wscale=sigma)
+        ctx.save_for_backward(x, wm, u.clone(), v.clone(), sigma, y if act != ACT_NONE else None)
+        ctx.cfg = (stride, pad, act, slope, bias is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, wm, u, v, sigma, y = ctx.saved_tensors
+        stride, pad, act, slope, has_bias = ctx.cfg
+        dy = to_nhwc(dy)
+        if act != ACT_NONE:
+            dy = _act_bwd(y, dy, act, slope)
+        n, c1, h, w = x.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_dgrad_impl(dy, wm, stride, pad, h, w, 0, c1, wscale=sigma)
+        if ctx.needs_input_grad[1]:
+            dwsn = _conv_wgrad_impl(x, None, dy, wm.shape, stride, pad)
+            rows = wm.shape[0]
+            cols = wm.numel() // rows
+            dw = torch.empty_like(wm)
+            ws = _ws(call('ssg_spectral_norm_workspace_bytes', rows, cols), wm.device)
+            call('ssg_spectral_norm_bwd_f32', ptr(dwsn), ptr(wm), rows, cols, ptr(u), ptr(v), ptr(sigma), ptr(dw), ptr(ws), stream_ptr())
+        if has_bias and ctx.needs_input_grad[4]:
+            db = _channel_sum(dy, wm.shape[0])
+        return dx, dw, None, None, db, None, None, None, None, None, None
+
+
+def conv2d_sn(x, weight_orig, u, v, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, n_power_iterations=1, eps=1e-12):
+    """Spectrally normalised conv2d: see _Conv2dSN.  `n_power_iterations = 0` in eval mode (no update of u, v)."""
+    _lib.require_gpu(x)
+    pad = tuple(int(p) for p in padding) if isinstance(padding, (tuple, list)) else int(padding)
+    return _Conv2dSN.apply(x, weight_orig, u, v, bias, int(stride), pad, int(act), float(slope), int(n_power_iterations), float(eps))
 
 
 def spectral_norm_weight(weight_orig, u, v, n_power_iterations=1, eps=1e-12):

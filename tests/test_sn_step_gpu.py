@@ -71,6 +71,9 @@ def test_sn_discriminator_in_the_gan_step(pkg, dev):
     inp = torch.randn(2, 3, 64, 64, generator=g).to(dev); tgt = (torch.rand(2, 3, 64, 64, generator=g) > 0.5).float().to(dev)
     calls = []
     D.register_forward_hook(lambda m, i, o: calls.append(o.detach().cpu().numpy().copy()))
+    fused = []
+    orig_sn = pkg.ops.conv2d_sn
+    pkg.ops.conv2d_sn = lambda *a, **k: (fused.append(1), orig_sn(*a, **k))[1]
     for s in range(2):
         del calls[:]
         loss, iou, dice, closs, adv_g, adv_d = pkg.train_seg_gan.gan_step(inp, tgt, G, D, pkg.losses.BCEDiceLoss(), nn.BCEWithLogitsLoss(),
@@ -97,6 +100,9 @@ def test_sn_discriminator_in_the_gan_step(pkg, dev):
         rd = gold['s%d_d_step_D' % s]
         numel = np.array([p.numel() for p in D.parameters()])
         assert (np.abs(pd[:, 1] - rd[:, 1]) <= 1e-5 * rd[:, 1] + (0.5 * numel + 2) * 2e-5 * (s + 1)).all()
+    pkg.ops.conv2d_sn = orig_sn
+    # the eight convs ran with the spectral norm inside the conv (sigma rides the weight pack; W / sigma never written out)
+    assert len(fused) == 2 * 3 * 8, len(fused)
     # eval mode: no power iteration (spectral_norm.py:99-101 passes module.training)
     D.eval()
     u0 = [m.weight_u.clone() for m in convs]
