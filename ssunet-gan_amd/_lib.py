@@ -135,7 +135,6 @@ SIGNATURES['ssg_add_bf16'] = [_P, _I, _P, _I, _L, _I, _P, _I, _P]
 SIGNATURES['ssg_convert_f32_to_bf16'] = [_P, _I, _L, _I, _P, _I, _P]
 SIGNATURES['ssg_convert_bf16_to_f32'] = [_P, _I, _L, _I, _P, _I, _P]
 _RESTYPES = {
-    'ssg_pack_weights_scaled_f32': [_P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _P, _P, _P],
     'ssg_conv2d_wgrad_workspace_bytes': C.c_int64,
     'ssg_bn_workspace_bytes': C.c_int64,
     'ssg_seg_loss_workspace_bytes': C.c_int64,
