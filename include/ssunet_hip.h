@@ -74,6 +74,8 @@ typedef struct {
   int in_sy, in_sx, out_sy, out_sx, out_oy, out_ox;
   int ntaps; int dy[SSG_MAX_TAPS]; int dx[SSG_MAX_TAPS];   /* each in [-2, 5] */
   int act; float slope;
+  double* bnpart;           /* optional batch-norm statistics of the OUTPUT (acc + bias, before res / act): one row [2][Cout]
+                             * (sum, sum of squares; fp64) per M-tile, ssg_conv2d_bnpart_rows(d) rows; NULL = off */
 } ssg_conv_desc;
 
 int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream);
@@ -88,6 +90,10 @@ int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream);
  * 10 = thin small-Cout (VALU; profiling labels). */
 int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream);
 int ssg_conv2d_kernel_id(const ssg_conv_desc* d);
+/* Rows of `bnpart` the launch for `d` writes, or 0 when the kernel `d` maps to has no statistics epilogue (the caller then
+ * runs ssg_bn_stats_f32).  The batch norm that follows the conv (archs.py:211,213; models_seg_gan.py:43) takes its
+ * (sum x, sum x^2) from these rows (ssg_bn_stats_from_partials_f32): one full read of the conv output less. */
+int ssg_conv2d_bnpart_rows(const ssg_conv_desc* d);
 
 /* Weight packing from the reference's OIHW parameter layout [O][I][KH][KW] (the
  * state_dict layout of nn.Conv2d, archs.py:210 etc.) into the [R][Kp] operand above.
@@ -210,6 +216,8 @@ int ssg_nhwc_to_nchw_f32(const float* src, int ld, int N, int C, int H, int W, f
  */
 int64_t ssg_bn_workspace_bytes(int64_t P, int C);
 int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, int with_count, void* ws, void* stream);
+/* stage 1 from the conv epilogue's per-tile rows (ssg_conv_desc.bnpart); count > 0 also writes sums[2C] = count */
+int ssg_bn_stats_from_partials_f32(const double* part, int rows, int C, double* sums, double count, void* stream);
 int ssg_bn_finalize_f32(const double* sums, double count, int C, const float* weight, const float* bias,
                         float eps, float momentum, int var_mode,
                         float* running_mean, float* running_var,

@@ -22,16 +22,17 @@ class _BasicBlockFn(torch.autograd.Function):
     def forward(ctx, x1, x2, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, wsc, eps1, mom1, eps2, mom2, stride, var_mode, group):
         x1 = to_nhwc(x1)
         x2 = to_nhwc(x2) if x2 is not None else None
-        c1 = _conv_fwd_impl(x1, x2, w1, None, stride, 1, ACT_NONE, 0.0)
-        y1, st1, cnt1 = _bn_fwd_impl(c1, g1, b1, rm1, rv1, None, eps1, mom1, ACT_RELU, 0.0, var_mode, group)
-        c2 = _conv_fwd_impl(y1, None, w2, None, 1, 1, ACT_NONE, 0.0)
+        # batch-norm statistics ride the producing conv's epilogue where its kernel has one (part = None otherwise)
+        c1, part1 = _conv_fwd_impl(x1, x2, w1, None, stride, 1, ACT_NONE, 0.0, want_bn=True)
+        y1, st1, cnt1 = _bn_fwd_impl(c1, g1, b1, rm1, rv1, None, eps1, mom1, ACT_RELU, 0.0, var_mode, group, part=part1)
+        c2, part2 = _conv_fwd_impl(y1, None, w2, None, 1, 1, ACT_NONE, 0.0, want_bn=True)
         if wsc is not None:
             sc = _conv_fwd_impl(x1, x2, wsc, None, stride, 0, ACT_NONE, 0.0)
         else:
             if x2 is not None:
                 raise ValueError('identity shortcut with a two-tensor input')
             sc = x1
-        out, st2, cnt2 = _bn_fwd_impl(c2, g2, b2, rm2, rv2, sc, eps2, mom2, ACT_RELU, 0.0, var_mode, group)
+        out, st2, cnt2 = _bn_fwd_impl(c2, g2, b2, rm2, rv2, sc, eps2, mom2, ACT_RELU, 0.0, var_mode, group, part=part2)
         ctx.save_for_backward(x1, x2, c1, y1, c2, out, w1, g1, w2, g2, wsc, st1, st2)
         ctx.cfg = (stride, group, cnt1, cnt2)
         return out

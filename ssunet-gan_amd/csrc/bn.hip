@@ -420,6 +420,14 @@ extern "C" int ssg_bn_stats_bf16(const void* x, int64_t P, int C, int ld, double
   return bn_stats_impl<ssg_bf16>((const ssg_bf16*)x, P, C, ld, sums, with_count, ws, stream);
 }
 
+extern "C" int ssg_bn_stats_from_partials_f32(const double* part, int rows, int C, double* sums, double count, void* stream) {
+  SSG_REQUIRE(part && sums && rows > 0 && C > 0, SSG_EINVAL, "bn_stats_from_partials: bad args");
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, (hipStream_t)stream, part, rows, C, C, sums,
+                     (float*)nullptr, count);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
 extern "C" int ssg_channel_sum_f32(const float* x, int64_t P, int C, int ld, float* out, void* ws, void* stream) {
   SSG_REQUIRE(x && out && ws && P > 0 && C > 0, SSG_EINVAL, "channel_sum: bad args");
   SSG_REQUIRE(ld % 4 == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN, "channel_sum: alignment");

@@ -5,6 +5,7 @@
 struct ConvArgs {
   const float* in1; const float* in2;
   const float* w; const float* bias; const float* res; float* out;
+  double* bnpart;                // optional [M-tile][2][Cout] per-tile (sum, sum of squares) of the outputs (acc + bias), or NULL
   int C1, C2, ld1, ld2;
   int N, H, W;
   int Kp, kmode;
@@ -27,3 +28,37 @@ int ssg_conv_dma_variant(const ConvArgs& a, int variant);    // 0 = <128,128>, 1
 bool ssg_conv_halo_ok(const ConvArgs& a);
 int ssg_conv_igemm_halo_launch(const ConvArgs& a, int variant, hipStream_t st);
 int ssg_conv_halo_variant(const ConvArgs& a, int variant);   // 0 = <128,128>, 1 = <256,64>, 2 = <128,64>
+
+// Batch-norm statistics in the conv epilogue (halo and DMA kernels): every lane adds up its output column over the rows it
+// holds (fp32, <= 32 values), the partials are widened to fp64, folded over the two lane halves and the WAVES_M waves, and
+// one row [2][Cout-slice] per workgroup goes to a.bnpart; ssg_bn_stats_from_partials_f32 adds the rows in order.
+template <int NI, int WAVES_M, int BN, int WTN>
+__device__ __forceinline__ void ssg_bnpart_store(const ConvArgs& a, float* lds_f, const float (&s1)[NI], const float (&s2)[NI], int mtile, int n0,
+                                                 int wm, int wn, int half, int l31) {
+  double* red = (double*)lds_f;                  // [WAVES_M][2][BN]
+  __syncthreads();                               // the K loop's LDS tiles are dead for every wave
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    double d1 = (double)s1[j], d2 = (double)s2[j];
+    d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
+    if (half == 0) {
+      red[(wm * 2 + 0) * BN + wn * WTN + j * 32 + l31] = d1;
+      red[(wm * 2 + 1) * BN + wn * WTN + j * 32 + l31] = d2;
+    }
+  }
+  __syncthreads();
+  if (wm == 0 && half == 0) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = wn * WTN + j * 32 + l31;
+      const int co = n0 + col;
+      if (co < a.Cout) {
+        double t1 = 0, t2 = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES_M; ++k) { t1 += red[(k * 2 + 0) * BN + col]; t2 += red[(k * 2 + 1) * BN + col]; }
+        double* dst = a.bnpart + (size_t)mtile * 2 * a.Cout;
+        dst[co] = t1; dst[a.Cout + co] = t2;
+      }
+    }
+  }
+}

@@ -265,6 +265,7 @@ int validate(const ssg_conv_desc* d) {
 ConvArgs to_args(const ssg_conv_desc* d) {
   ConvArgs a;
   a.in1 = d->in1; a.in2 = d->C2 ? d->in2 : d->in1; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out;
+  a.bnpart = d->bnpart;
   a.C1 = d->C1; a.C2 = d->C2; a.ld1 = d->ld1; a.ld2 = d->C2 ? d->ld2 : d->ld1;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Kp = d->Kp; a.kmode = d->kmode;
   a.ldr = d->ldr; a.Cout = d->Cout; a.ldo = d->ldo;
@@ -283,11 +284,24 @@ ConvArgs to_args(const ssg_conv_desc* d) {
 
 }  // namespace
 
+// rows of the batch-norm partial buffer the launch for `d` writes (one per M-tile), or 0 when the kernel `d` maps to has no
+// statistics epilogue (thin / register-staged kernels): the caller then runs ssg_bn_stats_f32 instead
+extern "C" int ssg_conv2d_bnpart_rows(const ssg_conv_desc* d) {
+  if (!d || validate(d) != SSG_OK) return 0;
+  if (ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d) || !uses_dma(d)) return 0;
+  const ConvArgs a = to_args(d);
+  int th, tw;
+  if (uses_halo(a)) { th = ssg_conv_halo_variant(a, pick_variant(d)) == 1 ? 8 : 4; tw = 32; }
+  else { th = ssg_conv_dma_variant(a, pick_variant(d)) == 1 ? 16 : 8; tw = 16; }
+  return ((d->GW + tw - 1) / tw) * ((d->GH + th - 1) / th) * d->N;
+}
+
 extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc != SSG_OK) return rc;
   const ConvArgs a = to_args(d);
   hipStream_t st = (hipStream_t)stream;
+  SSG_REQUIRE(!d->bnpart || uses_dma(d), SSG_EINVAL, "conv: bnpart given but this shape has no statistics epilogue (ssg_conv2d_bnpart_rows == 0)");
   if (uses_dma(d)) {
     if (uses_halo(a)) return ssg_conv_igemm_halo_launch(a, pick_variant(d), st);
     return ssg_conv_igemm_dma_launch(a, pick_variant(d), st);
@@ -318,8 +332,9 @@ extern "C" int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc != SSG_OK) return rc;
   const int k4 = ssg_thin4_conv_kind(d);
+  const int k = k4 ? 0 : ssg_thin_conv_kind(d);
+  SSG_REQUIRE(!d->bnpart || !(k4 || k), SSG_EINVAL, "conv: bnpart given but this shape has no statistics epilogue (ssg_conv2d_bnpart_rows == 0)");
   if (k4) return ssg_thin4_conv_launch(d, k4, (hipStream_t)stream);
-  const int k = ssg_thin_conv_kind(d);
   if (k) return ssg_thin_conv_launch(d, k, (hipStream_t)stream);
   return ssg_conv2d_igemm_f32(d, stream);
 }

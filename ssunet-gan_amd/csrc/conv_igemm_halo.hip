@@ -193,11 +193,14 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
 #endif
 
   // ---- epilogue (identical to conv_igemm.hip): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool want_bn = a.bnpart != nullptr;
+  float bn1[NI], bn2[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn * WTN + j * 32 + l31;
     const bool cok = co < a.Cout;
     const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -207,6 +210,7 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
         if (gy < a.GH && gx < a.GW) {
           const size_t pix = ((size_t)(n * a.OH + gy * a.out_sy + a.out_oy) * a.OW + gx * a.out_sx + a.out_ox);
           float v = acc[i][j][r] + bv;
+          if (want_bn) { s1 += v; s2 += v * v; }
           if (cok) {
             if (a.res) v += a.res[pix * a.ldr + co];
             if (a.act == SSG_ACT_RELU) v = v < 0.f ? 0.f : v;
@@ -218,7 +222,9 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
         }
       }
     }
+    bn1[j] = s1; bn2[j] = s2;
   }
+  if (want_bn) ssg_bnpart_store<NI, WAVES_M, BN, WTN>(a, lds, bn1, bn2, (n * a.tiles_y + ty) * a.tiles_x + tx, n0, wm, wn, half, l31);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>

@@ -59,13 +59,17 @@ class ConvolutionalBlock(nn.Module):
                 return ops.conv2d_sn(input, conv.weight_orig, conv.weight_u, conv.weight_v, conv.bias, conv.stride[0], conv.padding[0],
                                      act=a, slope=sl, n_power_iterations=sn.n_power_iterations if conv.training else 0, eps=sn.eps)
         else:
-            def run(a, sl):
-                return ops.conv2d(input, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act=a, slope=sl)
+            def run(a, sl, bn_stats=False):
+                return ops.conv2d(input, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act=a, slope=sl, bn_stats=bn_stats)
         if not self._bn:
             return run(act, slope)
-        y = run(ACT_NONE, 0.0)
         bn = self.conv_block[1]
-        return ops.batch_norm_act(y, bn, act=act, slope=slope, group=getattr(bn, '_ssg_sync_group', None))
+        part = None
+        if sn is None and bn.training:
+            y, part = run(ACT_NONE, 0.0, bn_stats=True)       # (sum, sum of squares) of y from the conv epilogue
+        else:
+            y = run(ACT_NONE, 0.0)
+        return ops.batch_norm_act(y, bn, act=act, slope=slope, group=getattr(bn, '_ssg_sync_group', None), stats_part=part)
 
 
 class Generator(nn.Module):

@@ -208,7 +208,9 @@ class _Timed(object):
 
 
 def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps, n, h, w, gh, gw, oh, ow,
-                 in_s, out_s, out_oy, out_ox, out):
+                 in_s, out_s, out_oy, out_ox, out, want_bn=False):
+    """Returns None, or -- with want_bn and a kernel that has the statistics epilogue -- the fp64 tensor [rows, 2, cout] of
+    per-tile (sum, sum of squares) of the conv output (ssg_conv_desc.bnpart)."""
     d = ConvDesc()
     d.in1 = x1.data_ptr(); d.C1 = pad4(x1.shape[1]); d.ld1 = _ld(x1)
     if x2 is not None:
@@ -229,6 +231,13 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     d.out_oy, d.out_ox = out_oy, out_ox
     _fill_taps(d, taps)
     d.act = act; d.slope = slope
+    d.bnpart = None
+    part = None
+    if want_bn and BN_EPILOGUE:
+        rows = call('ssg_conv2d_bnpart_rows', C.byref(d))
+        if rows > 0:
+            part = torch.empty((rows, 2, cout), dtype=torch.float64, device=out.device)
+            d.bnpart = part.data_ptr()
     cred = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
     label = None
     if PROFILE is not None:
@@ -237,6 +246,12 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
             label += ' n%d %dx%d cin%d cout%d taps%d s%d/%d' % (n, gh, gw, cred, cout, len(taps), in_s, out_s)
     with _Timed(label, 2.0 * n * gh * gw * cout * cred * len(taps)):
         call('ssg_conv2d_f32', C.byref(d), stream_ptr())
+    return part
+
+
+# SSG_BN_EPILOGUE=0: batch-norm statistics from their own pass over the conv output instead of the conv epilogue (A/B switch)
+import os as _os
+BN_EPILOGUE = _os.environ.get('SSG_BN_EPILOGUE', '1') != '0'
 
 
 def _out_size(h, k, s, p):
@@ -248,7 +263,9 @@ def _out_hw(h, w, kh, kw, s, pad):
     return (h + pt + pb - kh) // s + 1, (w + pl + pr - kw) // s + 1
 
 
-def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=None, wscale=None):
+def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=None, wscale=None, want_bn=False):
+    """Returns y, or (y, part) with want_bn: part = per-tile batch-norm partial sums of y from the conv epilogue, or None when
+    the kernel this shape maps to has none (the batch norm then runs its own statistics pass)."""
     o, i, kh, kw = weight.shape
     n, c1, h, w = x1.shape
     c2 = x2.shape[1] if x2 is not None else 0
@@ -262,8 +279,9 @@ def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=
     oh, ow = _out_hw(h, w, kh, kw, stride, pad)
     if out is None:
         out = new_nhwc(n, o, oh, ow, x1.device)
-    _conv_launch(x1, x2, wpk, kp, kmode, 0, o, bias, res, act, slope, taps, n, h, w, oh, ow, oh, ow, stride, 1, 0, 0, out)
-    return out
+    part = _conv_launch(x1, x2, wpk, kp, kmode, 0, o, bias, res, act, slope, taps, n, h, w, oh, ow, oh, ow, stride, 1, 0, 0, out,
+                        want_bn=want_bn and res is None and act == ACT_NONE)
+    return (out, part) if want_bn else out
 
 
 def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None, wscale=None):
@@ -353,20 +371,24 @@ class _Conv2d(torch.autograd.Function):
     """F.conv2d (+bias, +activation, optional second input = channel concat) on MFMA."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, stride, pad, act, slope, res=None):
+    def forward(ctx, x1, x2, weight, bias, stride, pad, act, slope, res=None, want_bn=False):
         x1 = to_nhwc(x1)
         x2 = to_nhwc(x2) if x2 is not None else None
         res = to_nhwc(res) if res is not None else None
-        y = _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=res)
+        y, part = _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=res, want_bn=True) if want_bn else \
+            (_conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=res), None)
         ctx.cfg = (stride, pad, act, slope)
         ctx.save_for_backward(x1, x2, weight, y if act != ACT_NONE else None)
         ctx.has_bias = bias is not None
         ctx.has_res = res is not None
-        return y
+        if part is None:
+            part = torch.empty(0, dtype=torch.float64, device=y.device)
+        ctx.mark_non_differentiable(part)
+        return y, part
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, _=None):
         x1, x2, weight, y = ctx.saved_tensors
         stride, pad, act, slope = ctx.cfg
         dy = to_nhwc(dy)
@@ -383,16 +405,19 @@ class _Conv2d(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = _channel_sum(dy, weight.shape[0])
         dres = dy if (ctx.has_res and ctx.needs_input_grad[8]) else None      # residual joins before the activation
-        return dx1, dx2, dw, db, None, None, None, None, dres
+        return dx1, dx2, dw, db, None, None, None, None, dres, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, x2=None, res=None):
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, slope=0.0, x2=None, res=None, bn_stats=False):
     """F.conv2d on the HIP kernels.  `padding`: int or (top, bottom, left, right) (TF-"same" static
     padding of the EfficientNet convs is asymmetric); `x2`: second tensor concatenated after x;
-    `res`: tensor added in the epilogue before the activation (act(conv(x) + bias + res))."""
+    `res`: tensor added in the epilogue before the activation (act(conv(x) + bias + res)).
+    `bn_stats=True`: returns (y, part) -- `part` are the per-tile (sum, sum of squares) of y from the conv epilogue (empty when
+    this shape's kernel has none); hand it to batch_norm_act(y, bn, stats_part=part) to skip its statistics pass."""
     _lib.require_gpu(x)
     pad = tuple(int(v) for v in padding) if isinstance(padding, (tuple, list)) else int(padding)
-    return _Conv2d.apply(x, x2, weight, bias, int(stride), pad, int(act), float(slope), res)
+    y, part = _Conv2d.apply(x, x2, weight, bias, int(stride), pad, int(act), float(slope), res, bool(bn_stats))
+    return (y, part) if bn_stats else y
 
 
 # ----------------------------------------------------------------------------- linear (as 1x1 conv over a 1 x N "image")
@@ -471,7 +496,7 @@ def _synced(group):
 _STATS_EPOCH = [0]
 
 
-def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group):
+def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part=None):
     """stats -> (all-reduce) -> finalize -> apply.  Returns (y, stats[4,C], count): `count` is None for a local batch norm
     and, when synchronised, the fp64[1] device tensor holding the all-reduced pixel count (ranks may hold unequal batches:
     the count travels with the sums instead of being assumed to be p * world)."""
@@ -481,9 +506,15 @@ def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum,
     p = n * h * w
     dev = x.device
     synced = _synced(group)
-    ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
     sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-    call('ssg_bn_stats_f32', ptr(x), p, c, _ld(x), ptr(sums), int(synced), ptr(ws), stream_ptr())
+    if part is not None and part.numel() > 0:
+        # (sum x, sum x^2) came out of the producing conv's epilogue, one row per tile: x is not read for its statistics
+        if part.shape[-1] != c or part.numel() % (2 * c):
+            raise ValueError('batch_norm: statistics partials %s do not fit C=%d' % (tuple(part.shape), c))
+        call('ssg_bn_stats_from_partials_f32', ptr(part), part.numel() // (2 * c), c, ptr(sums), float(p) if synced else 0.0, stream_ptr())
+    else:
+        ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
+        call('ssg_bn_stats_f32', ptr(x), p, c, _ld(x), ptr(sums), int(synced), ptr(ws), stream_ptr())
     if synced:
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     stats = torch.empty((4, c), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
@@ -538,7 +569,7 @@ class _BatchNormAct(torch.autograd.Function):
     run on the padded lanes too: zero data with zero weight/bias stays zero."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group):
+    def forward(ctx, x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part=None):
         x = to_nhwc(x)
         res = to_nhwc(res) if res is not None else None
         c = x.shape[1]
@@ -556,7 +587,7 @@ class _BatchNormAct(torch.autograd.Function):
                 running_var.copy_(rv[:c])
             weight = wp
         else:
-            y, stats, cnt = _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group)
+            y, stats, cnt = _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part=part)
         ctx.save_for_backward(x, y if (act != ACT_NONE and res is not None) else None, weight, stats)   # no residual: mask is recomputed
         ctx.cfg = (act, slope, group, cnt, res is not None, c)
         return _relabel(y, c) if c4 != c else y
@@ -576,7 +607,7 @@ class _BatchNormAct(torch.autograd.Function):
             dx = _relabel(dx, c)
             dres = _relabel(dres, c) if dres is not None else None
             dw, db = dw[:c].clone(), db[:c].clone()
-        return dx, dw, db, None, None, dres, None, None, None, None, None, None
+        return dx, dw, db, None, None, dres, None, None, None, None, None, None, None
 
 
 class _AffineAct(torch.autograd.Function):
@@ -597,8 +628,9 @@ class _AffineAct(torch.autograd.Function):
         raise NotImplementedError('eval-mode batch norm is inference-only in ssunet-gan_amd')
 
 
-def batch_norm_act(x, bn, res=None, act=ACT_NONE, slope=0.0, group=None, var_mode=None):
-    """nn.BatchNorm2d `bn` (any _BatchNorm holding weight/bias/running stats) + residual + activation."""
+def batch_norm_act(x, bn, res=None, act=ACT_NONE, slope=0.0, group=None, var_mode=None, stats_part=None):
+    """nn.BatchNorm2d `bn` (any _BatchNorm holding weight/bias/running stats) + residual + activation.
+    `stats_part`: the per-tile statistics the producing conv2d(..., bn_stats=True) returned (train mode only)."""
     _lib.require_gpu(x)
     if bn.training or not bn.track_running_stats:
         if bn.momentum is None:
@@ -609,7 +641,7 @@ def batch_norm_act(x, bn, res=None, act=ACT_NONE, slope=0.0, group=None, var_mod
             var_mode = getattr(bn, '_ssg_var_mode', 1 if group is not None else 0)
         return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                                    bn.running_var if bn.track_running_stats else None, res, float(bn.eps), float(bn.momentum),
-                                   int(act), float(slope), int(var_mode), group)
+                                   int(act), float(slope), int(var_mode), group, stats_part)
     with torch.no_grad():
         scale = torch.rsqrt(bn.running_var + bn.eps)
         if bn.weight is not None:

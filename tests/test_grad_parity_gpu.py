@@ -48,17 +48,18 @@ class _Capture(object):
         pools0 = ops.max_pool2x2_skip
         cap = self
 
-        def bn(x, weight, bias, rm, rv, res, eps, momentum, act, slope, var_mode, group):
-            r = bn0(x, weight, bias, rm, rv, res, eps, momentum, act, slope, var_mode, group)
+        def bn(x, weight, bias, rm, rv, res, eps, momentum, act, slope, var_mode, group, **kw):
+            r = bn0(x, weight, bias, rm, rv, res, eps, momentum, act, slope, var_mode, group, **kw)
             if act != 0:
                 cap.items.append(cap._nchw_mask(r[0]))
             return r
 
-        def conv(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=None):
-            y = conv0(x1, x2, weight, bias, stride, pad, act, slope, res=res, out=out)
+        def conv(x1, x2, weight, bias, stride, pad, act, slope, **kw):
+            r = conv0(x1, x2, weight, bias, stride, pad, act, slope, **kw)
+            y = r[0] if isinstance(r, tuple) else r
             if act != 0 and not cap._mute:
                 cap.items.append(cap._nchw_mask(y))
-            return y
+            return r
 
         def pool(x):
             y, idx = pool0(x)
