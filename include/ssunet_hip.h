@@ -217,7 +217,8 @@ int ssg_nhwc_to_nchw_f32(const float* src, int ld, int N, int C, int H, int W, f
 int64_t ssg_bn_workspace_bytes(int64_t P, int C);
 int ssg_bn_stats_f32(const float* x, int64_t P, int C, int ld, double* sums, int with_count, void* ws, void* stream);
 /* stage 1 from the conv epilogue's per-tile rows (ssg_conv_desc.bnpart); count > 0 also writes sums[2C] = count */
-int ssg_bn_stats_from_partials_f32(const double* part, int rows, int C, double* sums, double count, void* stream);
+int64_t ssg_bn_stats_from_partials_workspace_bytes(int rows, int C);
+int ssg_bn_stats_from_partials_f32(const double* part, int rows, int C, double* sums, double count, void* ws, void* stream);
 int ssg_bn_finalize_f32(const double* sums, double count, int C, const float* weight, const float* bias,
                         float eps, float momentum, int var_mode,
                         float* running_mean, float* running_var,

@@ -62,7 +62,8 @@ SIGNATURES = {
     'ssg_conv2d_f32': [C.POINTER(ConvDesc), _P],
     'ssg_conv2d_kernel_id': [C.POINTER(ConvDesc)],
     'ssg_conv2d_bnpart_rows': [C.POINTER(ConvDesc)],
-    'ssg_bn_stats_from_partials_f32': [_P, _I, _I, _P, _D, _P],
+    'ssg_bn_stats_from_partials_workspace_bytes': [_I, _I],
+    'ssg_bn_stats_from_partials_f32': [_P, _I, _I, _P, _D, _P, _P],
     'ssg_conv2d_wgrad_kernel_id': [C.POINTER(WgradDesc)],
     'ssg_pack_weights_f32': [_P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _P, _P],
     'ssg_pack_weights_scaled_f32': [_P, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _P, _P, _P],
@@ -146,6 +147,7 @@ _RESTYPES = {
     'ssg_linear_fwd_workspace_bytes': C.c_int64,
     'ssg_sample_channel_sum_workspace_bytes': C.c_int64,
     'ssg_gemm_wgrad_bf16_workspace_bytes': C.c_int64,
+    'ssg_bn_stats_from_partials_workspace_bytes': C.c_int64,
 }
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id'}
 

@@ -420,10 +420,48 @@ extern "C" int ssg_bn_stats_bf16(const void* x, int64_t P, int C, int ld, double
   return bn_stats_impl<ssg_bf16>((const ssg_bf16*)x, P, C, ld, sums, with_count, ws, stream);
 }
 
-extern "C" int ssg_bn_stats_from_partials_f32(const double* part, int rows, int C, double* sums, double count, void* stream) {
-  SSG_REQUIRE(part && sums && rows > 0 && C > 0, SSG_EINVAL, "bn_stats_from_partials: bad args");
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, (hipStream_t)stream, part, rows, C, C, sums,
-                     (float*)nullptr, count);
+namespace {
+// The conv epilogue leaves one row per M-tile (up to 32 768 rows for a 64-channel layer at 16 x 512^2): folding them with
+// col_reduce_final_kernel alone would put C/32 workgroups on tens of MB.  First fold slices of rows in parallel (grid.y),
+// 32 channels x 8 row-lanes per block, rows of a lane in order, lanes in order: a fixed summation order.
+constexpr int FOLD_Z = 64;
+__global__ __launch_bounds__(256) void bnpart_fold_kernel(const double* __restrict__ part, int rows, int C, int rows_per_z,
+                                                          double* __restrict__ out /* [gridDim.y][2][C] */) {
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int r0 = blockIdx.y * rows_per_z;
+  int r1 = r0 + rows_per_z; if (r1 > rows) r1 = rows;
+  double a1 = 0, a2 = 0;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 8) { a1 += part[(size_t)r * 2 * C + c]; a2 += part[(size_t)r * 2 * C + C + c]; }
+  red[0][rl][cl] = a1; red[1][rl][cl] = a2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double t1 = 0, t2 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { t1 += red[0][k][cl]; t2 += red[1][k][cl]; }
+    out[(size_t)blockIdx.y * 2 * C + c] = t1; out[(size_t)blockIdx.y * 2 * C + C + c] = t2;
+  }
+}
+}  // namespace
+
+extern "C" int64_t ssg_bn_stats_from_partials_workspace_bytes(int rows, int C) {
+  return rows > 4 * FOLD_Z ? (int64_t)FOLD_Z * 2 * C * (int64_t)sizeof(double) : 16;
+}
+
+extern "C" int ssg_bn_stats_from_partials_f32(const double* part, int rows, int C, double* sums, double count, void* ws, void* stream) {
+  SSG_REQUIRE(part && sums && ws && rows > 0 && C > 0, SSG_EINVAL, "bn_stats_from_partials: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const double* src = part; int nrows = rows;
+  if (rows > 4 * FOLD_Z) {
+    const int rpz = (rows + FOLD_Z - 1) / FOLD_Z;
+    const int nz = (rows + rpz - 1) / rpz;
+    hipLaunchKernelGGL(bnpart_fold_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)nz), dim3(256), 0, st, part, rows, C, rpz, (double*)ws);
+    SSG_LAUNCH_CHECK();
+    src = (const double*)ws; nrows = nz;
+  }
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, src, nrows, C, C, sums, (float*)nullptr, count);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -511,7 +511,9 @@ def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum,
         # (sum x, sum x^2) came out of the producing conv's epilogue, one row per tile: x is not read for its statistics
         if part.shape[-1] != c or part.numel() % (2 * c):
             raise ValueError('batch_norm: statistics partials %s do not fit C=%d' % (tuple(part.shape), c))
-        call('ssg_bn_stats_from_partials_f32', ptr(part), part.numel() // (2 * c), c, ptr(sums), float(p) if synced else 0.0, stream_ptr())
+        rows = part.numel() // (2 * c)
+        ws = _ws(call('ssg_bn_stats_from_partials_workspace_bytes', rows, c), dev)
+        call('ssg_bn_stats_from_partials_f32', ptr(part), rows, c, ptr(sums), float(p) if synced else 0.0, ptr(ws), stream_ptr())
     else:
         ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
         call('ssg_bn_stats_f32', ptr(x), p, c, _ld(x), ptr(sums), int(synced), ptr(ws), stream_ptr())
