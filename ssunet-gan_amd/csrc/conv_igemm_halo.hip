@@ -26,6 +26,10 @@ namespace {
 
 __device__ __attribute__((aligned(64))) float ssg_zero_page_h[64];
 
+#ifndef SSG_HALO_EXP
+#define SSG_HALO_EXP 0     // ablation builds (tools/micro_halo_exp.py), never shipped: 1 = one barrier per chunk instead of per
+#endif                     // step, 2 = no weight DMA, 3 = both, 4 = s_setprio around the MFMA block, 5/6/7 = A / B / both DMA sources = zero page, 8 = contiguous B pieces
+
 
 
 #ifdef SSG_CLOCK_PROBE
@@ -98,6 +102,9 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
     const float* src; int ld, cc;
     if (c0 < a.C1) { src = a.in1; ld = a.ld1; cc = c0; } else { src = a.in2; ld = a.ld2; cc = c0 - a.C1; }
     const float* p = (chunk < nchunks && a_pix[k] >= 0) ? src + (size_t)a_pix[k] * ld + cc + a_q[k] : zero;
+#if SSG_HALO_EXP == 5 || SSG_HALO_EXP == 7
+    p = zero + (lane & 3) * 4;                           // every A piece from the (cache-resident) zero page
+#endif
     dma16(p, dst);
   };
   auto issue_b = [&](int s) {
@@ -105,6 +112,12 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
 #pragma unroll
     for (int j = 0; j < B_PC; ++j) {
       const float* p = (b_src[j] && s < nsteps) ? b_src[j] + (size_t)s * 16 : zero;
+#if SSG_HALO_EXP == 6 || SSG_HALO_EXP == 7
+      p = zero + (lane & 3) * 4;                         // every B piece from the zero page
+#endif
+#if SSG_HALO_EXP == 8                                    // B pieces from 1-KiB contiguous runs (what a step-major pack would give)
+      if (s < nsteps) p = a.w + ((size_t)(n0 / BN) * nsteps + s) * BSTG + (wave * B_PC + j) * 256 + lane * 4;
+#endif
       dma16(p, st + (wave * B_PC + j) * 256);
     }
   };
@@ -153,10 +166,18 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
       if (tp < APW - 1) wait_vmcnt<B_PC + 1>();
       else if (tp == APW - 1) { if (has_last) wait_vmcnt<B_PC + 1>(); else wait_vmcnt<B_PC>(); }
       else wait_vmcnt<B_PC>();
+#if SSG_HALO_EXP == 1 || SSG_HALO_EXP == 3
+      if (t == 0) __builtin_amdgcn_s_barrier();
+#else
       __builtin_amdgcn_s_barrier();
+#endif
       asm volatile("" ::: "memory");
       if (t < APW) issue_a(chunk + 1, t);
+#if SSG_HALO_EXP == 2 || SSG_HALO_EXP == 3
+      if (t >= APW) dma16(zero, ldsB + (s % 3) * BSTG + wave * 256);     // keeps the vmcnt arithmetic alive with one piece
+#else
       issue_b(s + 2);
+#endif
 
       const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
       const int toff = ((tb & 7) - 2) * HW + ((tb >> 3) - 2);          // dy*HW + dx
@@ -173,6 +194,9 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
         const int bq = h == 0 ? bq0 : bq1;
 #pragma unroll
         for (int j = 0; j < NI; ++j) fb[j] = *(const f32x4*)(Bb + j * 32 * 16 + bq);
+#if SSG_HALO_EXP == 4
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -180,6 +204,9 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
 #pragma unroll
             for (int j = 0; j < NI; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+#if SSG_HALO_EXP == 4
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
     }
   }
