@@ -76,7 +76,14 @@ typedef struct {
   int act; float slope;
   double* bnpart;           /* optional batch-norm statistics of the OUTPUT (acc + bias, before res / act): one row [2][Cout]
                              * (sum, sum of squares; fp64) per M-tile, ssg_conv2d_bnpart_rows(d) rows; NULL = off */
+  float* ws; int64_t ws_bytes;  /* optional split-K workspace (ssg_conv2d_workspace_bytes(d) bytes, 16-byte aligned); NULL = never split */
 } ssg_conv_desc;
+
+/* Launches whose pixel-tile count leaves most of the chip idle (the 16x16 / 32x32 levels of archs.py:583-589, the
+ * Cout <= 64 input gradients of SPADE's gamma|beta conv normalization.py:94-96, batch-1 inference api.py:322) split the
+ * reduction over 16-channel chunks into slabs; an ordered second stage adds the slabs and applies bias / res / act
+ * (bitwise reproducible).  Returns 0 when the launch for `d` would not split. */
+int64_t ssg_conv2d_workspace_bytes(const ssg_conv_desc* d);
 
 int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream);
 /* Dispatching entry point (what the host side calls): convs with <= 8 channels on one side and
@@ -85,7 +92,7 @@ int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream);
  * else goes to the MFMA implicit GEMM above.  Same descriptor, same semantics.
  * ssg_conv2d_kernel_id: 0..2 = conv_igemm_kernel<128,128>/<256,64>/<256,32> (register-staged),
  * 30/31/32 = conv_igemm_halo_kernel<128,128>/<256,64>/<128,64> (LDS-resident halo tile: the default for the 9 taps of
- * a 3x3 window at unit stride), 20/21/22 = conv_igemm_dma_kernel<128,128>/<256,64>/<128,64> (LDS-DMA pipeline, the default for Cin % 16 == 0
+ * a 3x3 window at unit stride), 33/34 = conv_igemm_halo16_kernel<128,128>/<128,64> (the same on 8x16-pixel tiles, images <= 16 wide), 20/21/22 = conv_igemm_dma_kernel<128,128>/<256,64>/<128,64> (LDS-DMA pipeline, the default for Cin % 16 == 0
  * and Cout > 32), 12/13 = thin4 kernels on the 4x4x1 MFMA (4-channel input / Cout <= 4 with Cin % 64 == 0),
  * 10 = thin small-Cout (VALU; profiling labels). */
 int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream);

@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ('ntaps', C.c_int), ('dy', C.c_int * MAX_TAPS), ('dx', C.c_int * MAX_TAPS),
         ('act', C.c_int), ('slope', C.c_float),
         ('bnpart', C.c_void_p),
+        ('ws', C.c_void_p), ('ws_bytes', C.c_int64),
     ]
 
 
@@ -62,6 +63,7 @@ SIGNATURES = {
     'ssg_conv2d_f32': [C.POINTER(ConvDesc), _P],
     'ssg_conv2d_kernel_id': [C.POINTER(ConvDesc)],
     'ssg_conv2d_bnpart_rows': [C.POINTER(ConvDesc)],
+    'ssg_conv2d_workspace_bytes': [C.POINTER(ConvDesc)],
     'ssg_bn_stats_from_partials_workspace_bytes': [_I, _I],
     'ssg_bn_stats_from_partials_f32': [_P, _I, _I, _P, _D, _P, _P],
     'ssg_conv2d_wgrad_kernel_id': [C.POINTER(WgradDesc)],
@@ -140,6 +142,7 @@ SIGNATURES['ssg_convert_f32_to_bf16'] = [_P, _I, _L, _I, _P, _I, _P]
 SIGNATURES['ssg_convert_bf16_to_f32'] = [_P, _I, _L, _I, _P, _I, _P]
 _RESTYPES = {
     'ssg_conv2d_wgrad_workspace_bytes': C.c_int64,
+    'ssg_conv2d_workspace_bytes': C.c_int64,
     'ssg_bn_workspace_bytes': C.c_int64,
     'ssg_seg_loss_workspace_bytes': C.c_int64,
     'ssg_dwconv2d_wgrad_workspace_bytes': C.c_int64,

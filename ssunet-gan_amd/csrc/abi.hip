@@ -11,4 +11,4 @@ void ssg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ssg_last_error(void) { return g_err; }
-extern "C" int ssg_abi_version(void) { return 2; }   // 2: round 2 (bf16 entry points, sync-BN count, no bnpart)
+extern "C" int ssg_abi_version(void) { return 3; }   // 3: ssg_conv_desc.ws / ws_bytes (split-K), ssg_conv2d_workspace_bytes

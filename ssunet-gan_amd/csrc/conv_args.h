@@ -17,6 +17,7 @@ struct ConvArgs {
   int act; float slope;
   int tiles_x, tiles_y, nsteps;
   int ntiles_n, xcd_swizzle;     // conv_igemm_dma.hip: Cout tiles (fastest workgroup index), XCD-contiguous tile map
+  float* ws; int ksplit;         // conv_igemm_halo.hip: split-K slabs [ksplit][N*GH*GW][pad4(Cout)] (ksplit <= 1: off)
 };
 
 
@@ -27,7 +28,9 @@ int ssg_conv_dma_variant(const ConvArgs& a, int variant);    // 0 = <128,128>, 1
 // conv_igemm_halo.hip: LDS-resident halo tile for the 9 taps of a 3x3 window (variant 0 = <128,128>, 1 = <256,64>)
 bool ssg_conv_halo_ok(const ConvArgs& a);
 int ssg_conv_igemm_halo_launch(const ConvArgs& a, int variant, hipStream_t st);
-int ssg_conv_halo_variant(const ConvArgs& a, int variant);   // 0 = <128,128>, 1 = <256,64>, 2 = <128,64>
+int ssg_conv_halo_variant(const ConvArgs& a, int variant);   // 0 = <128,128>, 1 = <256,64>, 2 = <128,64>, 3 / 4 = <128,128> / <128,64> on 8x16-pixel tiles
+void ssg_conv_halo_tile(int halo_variant, int* th, int* tw, int* bn);
+int ssg_conv_halo_ksplit(const ConvArgs& a, int variant);    // split-K slabs the launch would use given a workspace (1 = none)
 
 // Batch-norm statistics in the conv epilogue (halo and DMA kernels): every lane adds up its output column over the rows it
 // holds (fp32, <= 32 values), the partials are widened to fp64, folded over the two lane halves and the WAVES_M waves, and

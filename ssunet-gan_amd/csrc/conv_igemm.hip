@@ -221,9 +221,19 @@ int pick_variant(const ssg_conv_desc* d) {
 
 // LDS-DMA pipeline (conv_igemm_dma.hip) for the dense layers; SSG_IGEMM_DMA=0 falls back to the
 // register-staged kernel (A/B switch for measurements).
+ConvArgs to_args(const ssg_conv_desc* d);
+bool uses_halo(const ConvArgs& a);
+
 bool uses_dma(const ssg_conv_desc* d) {
   static const int use_dma = [] { const char* e = getenv("SSG_IGEMM_DMA"); return e ? atoi(e) : 1; }();
-  return use_dma && d->kmode == 0 && d->Cout > 32;
+  if (!use_dma || d->kmode != 0) return false;
+  if (d->Cout > 32) return true;
+  // Cout 17..32 on a small pixel grid with a long reduction (the input gradient of SPADE's gamma|beta conv at the 32x32
+  // level: 1024 -> 32 on 16 384 pixels = 64 tiles of the 256x32 register kernel): the 64-wide halo tile multiplies half
+  // its columns by zero weights but splits K over the idle CUs (15 -> > 60 TFLOP/s)
+  static const int narrow = [] { const char* e = getenv("SSG_HALO_NARROW"); return e ? atoi(e) : 1; }();
+  return narrow && d->Cout > 16 && d->ntaps == 9 && d->in_sy == 1 && d->in_sx == 1 && d->C1 + d->C2 >= 256 &&
+         (long long)d->N * d->GH * d->GW <= 32768 && uses_halo(to_args(d));
 }
 
 // LDS-resident halo tile (conv_igemm_halo.hip) for the 3x3 window; SSG_IGEMM_HALO=0 switches it off (A/B)
@@ -279,6 +289,7 @@ ConvArgs to_args(const ssg_conv_desc* d) {
   a.act = d->act; a.slope = d->slope;
   a.nsteps = d->Kp / 16;
   a.tiles_x = a.tiles_y = 0;
+  a.ws = nullptr; a.ksplit = 1;
   return a;
 }
 
@@ -291,16 +302,41 @@ extern "C" int ssg_conv2d_bnpart_rows(const ssg_conv_desc* d) {
   if (ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d) || !uses_dma(d)) return 0;
   const ConvArgs a = to_args(d);
   int th, tw;
-  if (uses_halo(a)) { th = ssg_conv_halo_variant(a, pick_variant(d)) == 1 ? 8 : 4; tw = 32; }
+  if (uses_halo(a)) {
+    if (d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) && ssg_conv_halo_ksplit(a, pick_variant(d)) > 1) return 0;   // split-K launch: no statistics epilogue
+    int bn; ssg_conv_halo_tile(ssg_conv_halo_variant(a, pick_variant(d)), &th, &tw, &bn);
+  }
   else { th = ssg_conv_dma_variant(a, pick_variant(d)) == 1 ? 16 : 8; tw = 16; }
   return ((d->GW + tw - 1) / tw) * ((d->GH + th - 1) / th) * d->N;
+}
+
+// bytes of ssg_conv_desc.ws with which the launch for `d` runs split-K (0: this shape / kernel does not split)
+static int64_t splitk_bytes(const ssg_conv_desc* d, int* ksplit) {
+  *ksplit = 1;
+  if (!uses_dma(d)) return 0;
+  const ConvArgs a = to_args(d);
+  if (!uses_halo(a) || d->ldo % 4 || ((uintptr_t)d->out & 15)) return 0;
+  const int k = ssg_conv_halo_ksplit(a, pick_variant(d));
+  if (k <= 1) return 0;
+  *ksplit = k;
+  return (int64_t)k * d->N * d->GH * d->GW * ((d->Cout + 3) & ~3) * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t ssg_conv2d_workspace_bytes(const ssg_conv_desc* d) {
+  if (!d || validate(d) != SSG_OK || ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d)) return 0;
+  int k;
+  return splitk_bytes(d, &k);
 }
 
 extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc != SSG_OK) return rc;
-  const ConvArgs a = to_args(d);
+  ConvArgs a = to_args(d);
   hipStream_t st = (hipStream_t)stream;
+  if (d->ws && !d->bnpart) {                 // split-K only with a workspace of the size ssg_conv2d_workspace_bytes reports
+    int k; const int64_t need = splitk_bytes(d, &k);
+    if (need > 0 && d->ws_bytes >= need && !((uintptr_t)d->ws & 15)) { a.ws = d->ws; a.ksplit = k; }
+  }
   SSG_REQUIRE(!d->bnpart || uses_dma(d), SSG_EINVAL, "conv: bnpart given but this shape has no statistics epilogue (ssg_conv2d_bnpart_rows == 0)");
   if (uses_dma(d)) {
     if (uses_halo(a)) return ssg_conv_igemm_halo_launch(a, pick_variant(d), st);
@@ -316,7 +352,7 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
 // Dispatcher: thin VALU kernels for the <= 8-channel cases, MFMA implicit GEMM otherwise.
 // ssg_conv2d_kernel_id reports which kernel a descriptor maps to (for profiling labels):
 //   0..2 = conv_igemm<128,128> / <256,64> / <256,32>, 20/21/22 = conv_igemm_dma<128,128> / <256,64> / <128,64>,
-//   30/31/32 = conv_igemm_halo<128,128> / <256,64> / <128,64>,
+//   30/31/32 = conv_igemm_halo<128,128> / <256,64> / <128,64>, 33/34 = conv_igemm_halo16<128,128> / <128,64> (8x16-pixel tiles),
 //   12 = thin4 (4x4x1 MFMA) 4-channel input, 13 = thin4 Cout <= 4, 10 = thin small-Cout (VALU).
 extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
   if (!d) return SSG_EINVAL;

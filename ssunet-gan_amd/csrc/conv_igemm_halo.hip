@@ -37,12 +37,20 @@ __device__ __attribute__((aligned(64))) float ssg_zero_page_h[64];
 __device__ unsigned long long* ssg_probe_buf = nullptr;
 #endif
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) {
-  constexpr int TH = BM / 32, TW = 32;
+// TWL = log2 of the tile width.  32-wide tiles keep the halo rows densely packed (pitch 34); the 16-wide tile (images
+// 16 pixels wide or less: a 32-wide tile would multiply half its rows by nothing) pads the halo pitch to 32 so that lanes
+// 16-31 of an M-fragment (the second image row) sit 32 halo rows after lanes 0-15 -- the same rows mod 16 as in the
+// dense case, i.e. the same conflict-free ds_read_b128 pattern.
+// Split-K (a.ksplit > 1): workgroup `slab` reduces the 16-channel chunks [slab*cps, (slab+1)*cps) only and writes its raw
+// partial sums to a.ws[slab][pixel of the launch grid][Cout4]; conv_splitk_reduce_kernel adds the slabs in order and
+// applies bias / residual / activation.  For launches whose tile count leaves most of the chip idle (the 16x16 and 32x32
+// levels, the Cout <= 64 input gradients of SPADE's gamma|beta conv, batch-1 inference).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int TWL, bool SPLIT>
+__device__ __forceinline__ void halo_body(const ConvArgs& a) {
+  constexpr int TW = 1 << TWL, TH = BM / TW;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / 32, NI = WTN / 32;
-  constexpr int HW = TW + 2, HR = (TH + 2) * HW;            // halo rows (one row = one pixel x 16 channels)
+  constexpr int HW = TWL == 5 ? TW + 2 : 32, HR = (TH + 2) * HW;   // halo pitch / rows (one row = one pixel x 16 channels)
   constexpr int AP = (HR + 15) / 16;                     // 1-KiB pieces per halo tile
   constexpr int APW = (AP + 3) / 4;                      // pieces per wave (dummy-padded), one per step
   constexpr int B_PC = BN / 64;                          // B pieces per wave per step
@@ -64,6 +72,8 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
   }
   const int nyt = a.ntiles_n;
   const int n0 = (bid % nyt) * BN; bid /= nyt;
+  int slab = 0;
+  if (SPLIT) { slab = bid % a.ksplit; bid /= a.ksplit; }
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
   const int n = bid / a.tiles_y;
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
     const int r = g * 16 + lr;
     const int hy = r / HW, hx = r - hy * HW;
     const int iy = ty * TH + hy - 1, ix = tx * TW + hx - 1;
-    const bool ok = g < AP && r < HR && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    const bool ok = g < AP && r < HR && hx < TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     a_pix[k] = ok ? (n * a.H + iy) * a.W + ix : -1;
     a_q[k] = 4 * (lp ^ ((r >> 2) & 3));
   }
@@ -90,7 +100,9 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
     b_src[j] = (n0 + r < a.Cout) ? a.w + (size_t)(n0 + r) * a.Kp + q : nullptr;
   }
   const float* zero = ssg_zero_page_h;
-  const int nchunks = (a.C1 + a.C2) >> 4;
+  const int cps = SPLIT ? (((a.C1 + a.C2) >> 4) + a.ksplit - 1) / a.ksplit : 0;      // chunks per slab
+  const int chunk0 = SPLIT ? slab * cps : 0;
+  const int nchunks = SPLIT ? min((a.C1 + a.C2) >> 4, chunk0 + cps) : (a.C1 + a.C2) >> 4;   // end of this workgroup's chunk range
   const int nsteps = nchunks * 9;
 
   // piece k of this wave for chunk `chunk` (a dummy zero-page piece past the last chunk or past AP)
@@ -136,16 +148,16 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int p = wm * WTM + i * 32 + l31;
-    rb[i] = ((p >> 5) + 1) * HW + (p & 31) + 1;
+    rb[i] = ((p >> TWL) + 1) * HW + (p & (TW - 1)) + 1;
   }
   const int swb = (l31 >> 2) & 3;
   const int bq0 = 4 * ((0 + half) ^ swb), bq1 = 4 * ((2 + half) ^ swb);
 
   // ---- prologue: halo of chunk 0, weights of steps 0 and 1
 #pragma unroll
-  for (int k = 0; k < APW; ++k) issue_a(0, k);
-  issue_b(0);
-  issue_b(1);
+  for (int k = 0; k < APW; ++k) issue_a(chunk0, k);
+  issue_b(chunk0 * 9);
+  issue_b(chunk0 * 9 + 1);
 
   // whether THIS wave issues an A piece at tap-step t (wave-uniform, but not compile-time for the last k)
   // -> make the count compile-time: waves without a k-th piece issue nothing and the wait is sized per wave
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
 #ifdef SSG_CLOCK_PROBE
   const unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  for (int chunk = chunk0; chunk < nchunks; ++chunk) {
     const float* Abuf = lds + (chunk & 1) * ABUF;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -220,6 +232,24 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
 #endif
 
   // ---- epilogue (identical to conv_igemm.hip): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (SPLIT) {                                           // raw partial sums of this slab; the reduce kernel finishes them
+    const int ldw = (a.Cout + 3) & ~3;
+    float* wsl = a.ws + (size_t)slab * a.N * a.GH * a.GW * ldw;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int co = n0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1));
+          if (gy < a.GH && gx < a.GW && co < ldw) wsl[((size_t)(n * a.GH + gy) * a.GW + gx) * ldw + co] = co < a.Cout ? acc[i][j][r] : 0.f;
+        }
+      }
+    }
+    return;
+  }
   const bool want_bn = a.bnpart != nullptr;
   float bn1[NI], bn2[NI];
 #pragma unroll
@@ -233,7 +263,7 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int p = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int gy = ty * TH + (p >> 5), gx = tx * TW + (p & 31);
+        const int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1));
         if (gy < a.GH && gx < a.GW) {
           const size_t pix = ((size_t)(n * a.OH + gy * a.out_sy + a.out_oy) * a.OW + gx * a.out_sx + a.out_ox);
           float v = acc[i][j][r] + bv;
@@ -255,20 +285,70 @@ __global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) 
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) { halo_body<BM, BN, WAVES_M, WAVES_N, 5, false>(a); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_halo16_kernel(const ConvArgs a) { halo_body<BM, BN, WAVES_M, WAVES_N, 4, false>(a); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int TWL>
+__global__ __launch_bounds__(256) void conv_igemm_halo_splitk_kernel(const ConvArgs a) { halo_body<BM, BN, WAVES_M, WAVES_N, TWL, true>(a); }
+
+// out = act(sum over slabs (in slab order) + bias + res): second stage of a split-K launch
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs a) {
+  const int ldw = (a.Cout + 3) & ~3, q4 = ldw >> 2;
+  const long long npix = (long long)a.N * a.GH * a.GW, total = npix * q4;
+  const size_t slab_stride = (size_t)npix * ldw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long gp = i / q4; const int c0 = 4 * (int)(i - gp * q4);
+    const float* src = a.ws + (size_t)gp * ldw + c0;
+    f32x4 v = *(const f32x4*)src;
+    for (int k = 1; k < a.ksplit; ++k) v += *(const f32x4*)(src + k * slab_stride);
+    const int gx = (int)(gp % a.GW); const long long t = gp / a.GW;
+    const int gy = (int)(t % a.GH), n = (int)(t / a.GH);
+    const size_t pix = ((size_t)(n * a.OH + gy * a.out_sy + a.out_oy) * a.OW + gx * a.out_sx + a.out_ox);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = c0 + e;
+      float x = v[e];
+      if (co < a.Cout) {
+        if (a.bias) x += a.bias[co];
+        if (a.res) x += a.res[pix * a.ldr + co];
+        if (a.act == SSG_ACT_RELU) x = x < 0.f ? 0.f : x;
+        else if (a.act == SSG_ACT_LRELU) x = x > 0.f ? x : x * a.slope;
+      } else x = 0.f;
+      o[e] = x;
+    }
+    *(f32x4*)(a.out + pix * a.ldo + c0) = o;
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int TWL>
 int launch(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
-  constexpr int TH = BM / 32;
-  constexpr int AP = ((TH + 2) * 34 + 15) / 16;
-  a.tiles_x = (a.GW + 31) / 32;
+  constexpr int TW = 1 << TWL, TH = BM / TW;
+  constexpr int AP = ((TH + 2) * (TWL == 5 ? TW + 2 : 32) + 15) / 16;
+  a.tiles_x = (a.GW + TW - 1) / TW;
   a.tiles_y = (a.GH + TH - 1) / TH;
   static const int swz = [] { const char* e = getenv("SSG_XCD_SWIZZLE"); return e ? atoi(e) : 1; }();
   a.xcd_swizzle = swz;
   a.ntiles_n = (a.Cout + BN - 1) / BN;
-  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
+  if (a.ksplit < 1) a.ksplit = 1;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n * a.ksplit));
   constexpr int lds_bytes = (2 * AP * 256 + 3 * BN * 16) * (int)sizeof(float);
   static_assert(lds_bytes <= 64 * 1024, "LDS budget");
-  hipLaunchKernelGGL((conv_igemm_halo_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
+  if (a.ksplit > 1) {
+    if constexpr (BM == 128 && !(BN == 128 && TWL == 5)) hipLaunchKernelGGL((conv_igemm_halo_splitk_kernel<BM, BN, WAVES_M, WAVES_N, TWL>), grid, dim3(256), lds_bytes, st, a);
+    else { ssg_set_error("conv halo: this tile has no split-K instantiation"); return SSG_EINVAL; }
+  } else if constexpr (TWL == 5) hipLaunchKernelGGL((conv_igemm_halo_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
+  else hipLaunchKernelGGL((conv_igemm_halo16_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
   SSG_LAUNCH_CHECK();
+  if (a.ksplit > 1) {
+    long long blocks = ((long long)a.N * a.GH * a.GW * (((a.Cout + 3) & ~3) >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    SSG_LAUNCH_CHECK();
+  }
   return SSG_OK;
 }
 
@@ -296,21 +376,55 @@ bool ssg_conv_halo_ok(const ConvArgs& a) {
 
 int ssg_conv_igemm_halo_launch(const ConvArgs& a, int variant, hipStream_t st) {
   switch (ssg_conv_halo_variant(a, variant)) {
-    case 0: return launch<128, 128, 2, 2>(a, st);
-    case 2: return launch<128, 64, 2, 2>(a, st);
-    default: return launch<256, 64, 4, 1>(a, st);
+    case 0: return launch<128, 128, 2, 2, 5>(a, st);
+    case 2: return launch<128, 64, 2, 2, 5>(a, st);
+    case 3: return launch<128, 128, 2, 2, 4>(a, st);
+    case 4: return launch<128, 64, 2, 2, 4>(a, st);
+    default: return launch<256, 64, 4, 1, 5>(a, st);
   }
+}
+
+// pixel-tile size of a variant (rows of the batch-norm partial buffer, split-K workspace geometry)
+void ssg_conv_halo_tile(int v, int* th, int* tw, int* bn) {
+  *tw = v >= 3 ? 16 : 32;
+  *th = (v == 1 ? 256 : 128) / *tw;
+  *bn = (v == 0 || v == 3) ? 128 : 64;
 }
 
 // 0 = <128,128> (Cout > 64), 1 = <256,64>, 2 = <128,64>: for Cout <= 64 with a short K loop (Cin <= 128: 36-72
 // steps per tile) four small workgroups per CU hide each other's prologue and epilogue better than two big ones
 // (measured at 16x512^2: Cin=64 108 -> 122 TFLOP/s, Cin=128 123 -> 128, Cin=192 132 -> 130)
+// 3 / 4 = <128,128> / <128,64> with 8 x 16-pixel tiles, for images at most 16 pixels wide.
 int ssg_conv_halo_variant(const ConvArgs& a, int variant) {
+  static const int w16 = [] { const char* e = getenv("SSG_HALO_W16"); return e ? atoi(e) : 1; }();
+  if (w16 && a.GW <= 16) return (variant == 0) ? 3 : 4;
   // Cout > 64 with Cin = 64 on the largest grids also prefers two <128,64> column tiles (110 -> 120 at 16x512^2)
-  if (variant == 0) {            // fewer than 3 workgroups per CU with 128x128 tiles: halve the tile (16x16 level)
+  if (variant == 0) {            // fewer than 3 workgroups per CU with 128x128 tiles: halve the tile (32x32 level)
     const long long wgs = (long long)a.N * ((a.GH + 3) / 4) * ((a.GW + 31) / 32) * ((a.Cout + 127) / 128);
     if (wgs < 768) return 2;
   }
   if (variant == 0) return ((a.C1 + a.C2) <= 64 && (long long)a.N * a.GH * a.GW >= (1ll << 22)) ? 2 : 0;
-  return (a.C1 + a.C2) <= 128 ? 2 : 1;
+  if ((a.C1 + a.C2) <= 128) return 2;
+  // Cout <= 64 with a long K loop: 256-pixel tiles, unless they leave CUs without a workgroup (the 32x32 / 64x64 levels)
+  return (long long)a.N * ((a.GH + 7) / 8) * ((a.GW + 31) / 32) < 512 ? 2 : 1;
+}
+
+// Split-K factor for a launch: as many slabs as bring the grid to ~3 workgroups per CU, each slab keeping at least 4
+// chunks (36 K-steps); 1 when the grid already fills the chip or no workspace was given.  SSG_HALO_SPLITK=0 switches it off.
+int ssg_conv_halo_ksplit(const ConvArgs& a, int variant) {
+  static const int on = [] { const char* e = getenv("SSG_HALO_SPLITK"); return e ? atoi(e) : 1; }();
+  if (!on || a.bnpart) return 1;
+  int th, tw, bn;
+  const int hv = ssg_conv_halo_variant(a, variant);
+  if (hv == 0 || hv == 1) return 1;                         // <128,128> / <256,64> on 32-wide tiles are only picked for grids that fill the chip
+  ssg_conv_halo_tile(hv, &th, &tw, &bn);
+  const long long wgs = (long long)a.N * ((a.GH + th - 1) / th) * ((a.GW + tw - 1) / tw) * ((a.Cout + bn - 1) / bn);
+  const int chunks = (a.C1 + a.C2) >> 4;
+  if (wgs >= 512 || chunks < 8) return 1;
+  long long k = (768 + wgs - 1) / wgs;
+  if (k > chunks / 4) k = chunks / 4;
+  if (k > 16) k = 16;
+  if (k < 2) return 1;
+  const int cps = (chunks + (int)k - 1) / (int)k;           // no empty slab
+  return (chunks + cps - 1) / cps;
 }

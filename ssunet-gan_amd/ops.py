@@ -182,6 +182,7 @@ PROFILE_SHAPES = False      # debug: append the launch geometry to the label
 _CONV_LABELS = {0: 'conv_igemm_kernel<128,128>', 1: 'conv_igemm_kernel<256,64>', 2: 'conv_igemm_kernel<256,32>',
                 20: 'conv_igemm_dma_kernel<128,128>', 21: 'conv_igemm_dma_kernel<256,64>', 22: 'conv_igemm_dma_kernel<128,64>',
                 30: 'conv_igemm_halo_kernel<128,128>', 31: 'conv_igemm_halo_kernel<256,64>', 32: 'conv_igemm_halo_kernel<128,64>',
+                33: 'conv_igemm_halo16_kernel<128,128>', 34: 'conv_igemm_halo16_kernel<128,64>',
                 10: 'thin_small_cout_kernel',
                 12: 'thin4_cin_kernel', 13: 'thin4_cout_kernel'}
 _WGRAD_LABELS = {0: 'wgrad_kernel<128,128>', 1: 'wgrad_kernel<128,64>', 2: 'wgrad_kernel<128,32>',
@@ -238,10 +239,17 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
         if rows > 0:
             part = torch.empty((rows, 2, cout), dtype=torch.float64, device=out.device)
             d.bnpart = part.data_ptr()
+    d.ws = None; d.ws_bytes = 0
+    ws = None
+    if part is None:                   # split-K (small pixel grids with a long reduction): the kernel needs a workspace
+        need = call('ssg_conv2d_workspace_bytes', C.byref(d))
+        if need > 0:
+            ws = _ws(need, out.device)
+            d.ws = ws.data_ptr(); d.ws_bytes = need
     cred = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
     label = None
     if PROFILE is not None:
-        label = _CONV_LABELS.get(call('ssg_conv2d_kernel_id', C.byref(d)), '?')
+        label = _CONV_LABELS.get(call('ssg_conv2d_kernel_id', C.byref(d)), '?') + ('+splitk' if ws is not None else '')
         if PROFILE_SHAPES:
             label += ' n%d %dx%d cin%d cout%d taps%d s%d/%d' % (n, gh, gw, cred, cout, len(taps), in_s, out_s)
     with _Timed(label, 2.0 * n * gh * gw * cout * cred * len(taps)):

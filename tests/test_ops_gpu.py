@@ -72,7 +72,14 @@ KERNEL_CASES = [
     (2, 64, 128, 37, 45, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<32,128>')),
     (4, 32, 128, 128, 192, 3, 1, ('conv_igemm_halo_kernel<128,128>', 'conv_igemm_kernel<256,32>', 'wgrad_halo_kernel<32,128>')),
     (1, 128, 64, 21, 70, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<64,64>')),
-    (1, 192, 64, 17, 40, 3, 1, ('conv_igemm_halo_kernel<256,64>', 'conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<64,64>')),
+    (1, 192, 64, 17, 40, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_halo_kernel<64,64>')),
+    (4, 144, 40, 64, 512, 3, 1, ('conv_igemm_halo_kernel<256,64>',)),                                      # >= 512 tiles of 256 pixels
+    # split-K (few pixel tiles, long reduction) and the 8x16-pixel tile (images <= 16 wide)
+    (2, 256, 256, 12, 14, 3, 1, ('conv_igemm_halo16_kernel<128,128>+splitk',)),
+    (2, 64, 128, 16, 16, 3, 1, ('conv_igemm_halo16_kernel<128,128>', 'conv_igemm_halo16_kernel<128,64>+splitk')),
+    (1, 512, 96, 20, 40, 3, 1, ('conv_igemm_halo_kernel<128,64>+splitk',)),
+    (2, 512, 32, 24, 24, 3, 1, ('conv_igemm_halo_kernel<128,64>+splitk',)),                               # Cout 17..32 on a small grid
+    (1, 256, 24, 10, 33, 3, 1, ('conv_igemm_halo_kernel<128,64>+splitk',)),
     (1, 96, 64, 9, 33, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_dma_kernel<128,64>')),
     (2, 48, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,128>')),            # short K: the small DMA tile
     (1, 320, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,128>', 'conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,128>')),
@@ -89,13 +96,18 @@ def test_conv2d_specialised_kernels(pkg, dev, case):
     b = torch.randn(cout, generator=g)
     rs = torch.randn(n, cout, h, w, generator=g)
     ref = [t.clone().requires_grad_(True) for t in (x, wt, b, rs)]
-    yr = F.leaky_relu(F.conv2d(ref[0], ref[1], ref[2], 1, p) + ref[3], 0.2)
+    # with millions of outputs some pre-activations land within fp32 rounding of 0 and the LeakyReLU mask (hence the
+    # gradient, by 0.8*dy*w) legitimately differs between two correct fp32 convolutions: the one large case runs without it
+    use_act = n * h * w * cout < 1000000
+    yr = F.conv2d(ref[0], ref[1], ref[2], 1, p) + ref[3]
+    if use_act:
+        yr = F.leaky_relu(yr, 0.2)
     dy = torch.randn(yr.shape, generator=g)
     yr.backward(dy)
     d = [t.to(dev).requires_grad_(True) for t in (x, wt, b, rs)]
     pkg.ops.PROFILE = []
     try:
-        yd = pkg.ops.conv2d(d[0], d[1], d[2], 1, p, act=pkg._lib.ACT_LRELU, slope=0.2, res=d[3])
+        yd = pkg.ops.conv2d(d[0], d[1], d[2], 1, p, act=pkg._lib.ACT_LRELU if use_act else pkg._lib.ACT_NONE, slope=0.2, res=d[3])
         yd.backward(dy.to(dev))
         labels = [rec[0] for rec in pkg.ops.PROFILE]
     finally:
@@ -167,7 +179,7 @@ def test_conv2d_concat_halo(pkg, dev):
         labels = [rec[0] for rec in pkg.ops.PROFILE]
     finally:
         pkg.ops.PROFILE = None
-    assert 'conv_igemm_halo_kernel<128,64>' in labels and 'wgrad_halo_kernel<32,128>' in labels, labels
+    assert any(l.startswith('conv_igemm_halo_kernel<128,64>') for l in labels) and 'wgrad_halo_kernel<32,128>' in labels, labels
     _close(yd, yr, 1e-5, 7e-5, 'concat halo conv')
     for a, b, nm in zip(d, r, ('dx1', 'dx2', 'dw')):
         _close(a.grad, b.grad, 2e-5, 7e-5, nm)
