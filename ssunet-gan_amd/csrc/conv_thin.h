@@ -10,3 +10,4 @@ int ssg_wgrad4_launch(const ssg_wgrad_desc* d, int kind, hipStream_t st);
 // conv_thin4.hip: thin convs on the 4x4x1 MFMA (kind 3 = in has 4 channels, 4 = Cout <= 4)
 int ssg_thin4_conv_kind(const ssg_conv_desc* d);
 int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st);
+int ssg_thin4_conv_id(const ssg_conv_desc* d, int kind);      // profiling label id (12..15)

@@ -167,6 +167,214 @@ __global__ __launch_bounds__(256) void thin4_cin_kernel(const T4Args a) {
   if (pend_ptr) *(f32x4*)pend_ptr = pend;
 }
 
+// ------------------------------------------------------------------ thin-Cin on the 32x32x2 MFMA: C == 4, 3x3 window, Cout >= 32
+// The 4x4x1 kernel above issues 36 MFMAs + ~90 other instructions per 1 KiB of output and is bound by instruction issue
+// (tools/micro_thin_exp.py: 0.30 ms of its 0.40 ms at 16 x 512^2, 4 -> 64, remain with the stores compiled out).  K = 9 taps x
+// 4 channels = 36 is exactly 18 K-steps of v_mfma_f32_32x32x2_f32, so the same FLOPs take 8x fewer MFMA instructions as a
+// plain GEMM: M = 32 consecutive pixels of one image row (lane&31), N = 2 x 32 output channels, and the lane half (lane>>5)
+// picks the channel pair {2h, 2h+1} of a tap -- one 8-byte load per (input row, dx) and lane, every input row loaded once per
+// strip and kept in a register ring for the three output rows that use it (as above).  A K-step is (tap, channel j of the
+// pair): A = in[y+dy][x+dx][2h+j], B = w[co][tap][2h+j] (36 registers per lane, loaded once).  The 32x32 accumulator tile
+// leaves each lane with 16 pixels of ONE channel: 32 dword stores per output row whose lanes 0-31 / 32-63 each cover one
+// whole 128-byte line (32 consecutive channels of a pixel).  All memory operations go through buffer descriptors (OOB
+// offset instead of branches).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 ldbuf2(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+}
+
+constexpr int RH_K36 = 16;       // output rows per work unit
+
+template <bool HAS_RES, int PF, bool NT>
+__global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
+  constexpr int AUX = NT ? 2 : 0;           // non-temporal stores for outputs far larger than the caches
+  constexpr int RING = 3 + PF;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int cg = wid % a.groups, wg = wid / a.groups;
+  if (wg >= a.waves_per_group) return;
+  const unsigned npix = (unsigned)(a.N * a.H * a.W);
+  const auto in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)(npix * (unsigned)a.ld * 4u), 0x00020000);
+  const auto out_rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(npix * (unsigned)a.ldo * 4u), 0x00020000);
+  const auto res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_RES ? a.res : a.in), 0,
+                                                        (int)(npix * (unsigned)(HAS_RES ? a.ldr : a.ld) * 4u), 0x00020000);
+  const unsigned ldb = (unsigned)a.ld * 4u, ldob = (unsigned)a.ldo * 4u, ldrb = (unsigned)a.ldr * 4u;
+
+  // B operand: K-step s = 2*p + j (p = window position, j = channel of the lane half's pair) for the lane's output channel
+  float wB[2][18], bv[2], keep[2];       // keep = 0 for the pad lanes [Cout, pad4(Cout)): written as 0
+  unsigned vo_out[2], vo_res[2];         // per-lane part of the byte offset (pixel 4*h of the strip, this lane's channel) or OOB
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int co = cg * 64 + f * 32 + l31;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      const int t = a.tapidx[p];
+      const bool ok = co < a.Cout && t >= 0;
+      const f32x2 w2 = ok ? *(const f32x2*)(a.w + (size_t)co * a.Kp + t * 4 + 2 * h) : f32x2{0.f, 0.f};
+      wB[f][2 * p] = w2[0]; wB[f][2 * p + 1] = w2[1];
+    }
+    bv[f] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    keep[f] = co < a.Cout ? 1.f : 0.f;
+    const bool cok = co < ((a.Cout + 3) & ~3);
+    vo_out[f] = cok ? 4u * (unsigned)h * ldob + (unsigned)co * 4u : OOB;
+    vo_res[f] = cok ? 4u * (unsigned)h * ldrb + (unsigned)co * 4u : OOB;
+  }
+  const bool is_relu = a.act == SSG_ACT_RELU;
+  const float neg_slope = a.act == SSG_ACT_LRELU ? a.slope : 1.f;
+
+  for (int u = wg; u < a.total_units; u += a.waves_per_group) {
+    const int xs = u % a.strips; const int r0 = u / a.strips;
+    const int yb = r0 % a.ybands, n = r0 / a.ybands;
+    const int x0 = xs * 32, x = x0 + l31;
+    const int y0 = yb * RH_K36;
+    const int y1 = y0 + RH_K36 < a.H ? y0 + RH_K36 : a.H;
+    unsigned coloff[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int ix = x + e - 1;
+      coloff[e] = (unsigned)ix < (unsigned)a.W ? (unsigned)ix * ldb + 8u * (unsigned)h : OOB;
+    }
+    const unsigned imgoff = (unsigned)(n * a.H) * (unsigned)a.W * ldb;
+    auto load_row = [&](f32x2* dst, int iy) {
+      const bool rok = (unsigned)iy < (unsigned)a.H;
+      const unsigned ro = imgoff + (unsigned)iy * (unsigned)a.W * ldb;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) dst[e] = ldbuf2(in_rs, (rok && coloff[e] != OOB) ? ro + coloff[e] : OOB);
+    };
+    // accumulator register q holds pixel column (q&3) + 8*(q>>2) + 4*h of the strip; bit q of `inw`: that column is inside the image
+    unsigned inw = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) inw |= (x0 + (q & 3) + 8 * (q >> 2) + 4 * h < a.W ? 1u : 0u) << q;
+    const bool full = x0 + 32 <= a.W;
+    f32x2 v[RING][3];
+#pragma unroll
+    for (int q = 0; q < 2 + PF; ++q) load_row(v[q], y0 - 1 + q);
+    auto mma_row = [&](f32x16 (&acc)[2], int r) {        // output row whose window rows sit in ring slots r, r+1, r+2
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[f][q] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+              acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[(r + q) % RING][e][j], wB[f][2 * (q * 3 + e) + j], acc[f], 0, 0, 0);
+    };
+    auto store_row_full = [&](const f32x16 (&acc)[2], int yy) {       // whole strip inside the image: per-lane offset is
+      const unsigned rowpix = (unsigned)((n * a.H + yy) * a.W + x0);  // loop-invariant, the rest rides the scalar offset
+      float rv[2][16];
+      const unsigned (&vo)[2] = vo_out; const unsigned (&vr)[2] = vo_res;
+      if (HAS_RES) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            rv[f][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                res_rs, vr[f], (int)((rowpix + (unsigned)((q & 3) + 8 * (q >> 2))) * ldrb), 0));
+      }
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float t = acc[f][q] + bv[f];
+          if (HAS_RES) t += rv[f][q];
+          t = (t < 0.f ? (is_relu ? 0.f : t * neg_slope) : t) * keep[f];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), out_rs, vo[f],
+                                                (int)((rowpix + (unsigned)((q & 3) + 8 * (q >> 2))) * ldob), AUX);
+        }
+    };
+    auto store_row_edge = [&](const f32x16 (&acc)[2], int yy) {       // a branch per access instead of 32 live offset registers
+      const unsigned rowpix = (unsigned)((n * a.H + yy) * a.W + x0);
+      if (yy >= y1) return;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          if ((inw >> q) & 1u) {
+            float t = acc[f][q] + bv[f];
+            if (HAS_RES) t += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                res_rs, vo_res[f], (int)((rowpix + (unsigned)((q & 3) + 8 * (q >> 2))) * ldrb), 0));
+            t = (t < 0.f ? (is_relu ? 0.f : t * neg_slope) : t) * keep[f];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), out_rs, vo_out[f],
+                                                  (int)((rowpix + (unsigned)((q & 3) + 8 * (q >> 2))) * ldob), AUX);
+          }
+        }
+    };
+    // (Issuing the MFMAs of row y+1 before the epilogue of row y, interleaved by sched_group_barrier, was measured: no gain
+    //  -- 0.319 vs 0.309 ms at 16 x 512^2, 4 -> 64 -- and 220-284 registers; the rows are processed one after the other.)
+    f32x16 acc[2];
+    for (int y = y0; y < y1; y += RING) {
+#pragma unroll
+      for (int r = 0; r < RING; ++r) {
+        if (y + r < y1) {
+          // input row y+r+1+PF goes into the slot of row y+r-2, whose last reader (output row y+r-1) is done
+          load_row(v[(r + 2 + PF) % RING], y + r + 1 + PF);
+          mma_row(acc, r);
+          if (full) store_row_full(acc, y + r);
+          else store_row_edge(acc, y + r);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ tiny: C == 4 AND Cout <= 8 (SPADE's 3 -> nhidden conv and its
+// input gradient at the 512^2 / 256^2 levels, normalization.py:92): 134 MB of traffic and 0.6 GFMA at 16 x 512^2.  One
+// thread per pixel on the VALU: 9 coalesced 16-byte loads (1 KiB per wave and tap), 36 * Cout FMAs whose weight operand is a
+// scalar register (uniform address -> s_load), one or two 16-byte stores.  The 4x4x1 kernel above spends a whole wave on 4
+// pixels for these shapes (0.55 ms per launch; this one: the traffic floor).
+template <int CO4>
+__global__ __launch_bounds__(256) void tiny4_kernel(const T4Args a) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long npix = (long long)a.N * a.H * a.W;
+  if (p >= npix) return;
+  const int x = (int)(p % a.W); const long long r0 = p / a.W;
+  const int y = (int)(r0 % a.H);
+  const auto in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((unsigned)npix * (unsigned)a.ld * 4u), 0x00020000);
+  const unsigned ldb = (unsigned)a.ld * 4u;
+  float acc[CO4 * 4];
+#pragma unroll
+  for (int co = 0; co < CO4 * 4; ++co) acc[co] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+  f32x4 v[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {                            // all loads first, none behind a branch
+    const int iy = y + q / 3 - 1, ix = x + q % 3 - 1;
+    const bool ok = a.tapidx[q] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    v[q] = ldbuf4(in_rs, ok ? (unsigned)(p + (long long)(q / 3 - 1) * a.W + (q % 3 - 1)) * ldb : OOB);
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int t = a.tapidx[q];
+    const float* wt = a.w + (t < 0 ? 0 : t) * 4;
+    const float on = t < 0 ? 0.f : 1.f;                    // a window position without a tap: its loads came back as 0 already
+#pragma unroll
+    for (int co = 0; co < CO4 * 4; ++co) {
+      const float* wr = wt + (size_t)(co < a.Cout ? co : 0) * a.Kp;
+      const float m = co < a.Cout ? on : 0.f;
+      acc[co] = fmaf(v[q][3], wr[3] * m, fmaf(v[q][2], wr[2] * m, fmaf(v[q][1], wr[1] * m, fmaf(v[q][0], wr[0] * m, acc[co]))));
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < CO4; ++g) {
+    if (4 * g < ((a.Cout + 3) & ~3)) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = 4 * g + e;
+        float t = acc[co];
+        if (a.res && co < a.Cout) t += a.res[p * a.ldr + co];
+        o[e] = co < a.Cout ? act_apply(t, a.act, a.slope) : 0.f;
+      }
+      *(f32x4*)(a.out + p * a.ldo + 4 * g) = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ thin-Cout: Cout <= 4*NG, C % 64 == 0
 // NG = 2 (Cout 5..8, e.g. the 128 -> 8 gamma/beta input gradients) runs two A-operand sets over the same loaded rows.
 template <int KS, int NG>
@@ -344,6 +552,26 @@ int ssg_thin4_conv_kind(const ssg_conv_desc* d) {
   return 0;
 }
 
+static bool routes_tiny(const ssg_conv_desc* d, int kind) {
+  static const int tiny = [] { const char* e = getenv("SSG_TINY4"); return e ? atoi(e) : 1; }();       // 0: 4x4x1 kernel (A/B switch)
+  return kind == 3 && tiny && d->Cout <= 8 && (long long)d->N * d->H * d->W * d->ld1 < (1ll << 30);
+}
+
+static bool routes_thin32(const ssg_conv_desc* d, int kind) {
+  static const int k36 = [] { const char* e = getenv("SSG_THIN32"); return e ? atoi(e) : 1; }();       // 0: 4x4x1 kernel (A/B switch)
+  if (kind != 3 || !k36 || d->Cout < 32 || (long long)d->N * d->H * d->W * d->ldo >= (1ll << 30)) return false;
+  if (d->W < 32 || (long long)d->N * d->H * d->W < 65536) return false;          // 32-pixel strips: small images stay on the 4-pixel kernel
+  for (int t = 0; t < d->ntaps; ++t) if (d->dy[t] || d->dx[t]) return true;       // a real window, not the 1x1 case
+  return false;
+}
+
+// profiling label: 12 = thin4_cin (4x4x1), 13 = thin4_cout, 14 = tiny4 (VALU), 15 = thin32_cin (32x32x2)
+int ssg_thin4_conv_id(const ssg_conv_desc* d, int kind) {
+  if (routes_tiny(d, kind)) return 14;
+  if (routes_thin32(d, kind)) return 15;
+  return 9 + kind;
+}
+
 int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
   T4Args a;
   a.in = d->in1; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out;
@@ -363,6 +591,33 @@ int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
   if (wpg > a.total_units) wpg = a.total_units;
   a.waves_per_group = wpg;
   const dim3 grid((unsigned)((wpg * a.groups + 3) / 4)), block(256);
+  if (routes_tiny(d, kind)) {
+    const dim3 gridt((unsigned)(((long long)d->N * d->H * d->W + 255) / 256));
+    if (d->Cout <= 4) hipLaunchKernelGGL(tiny4_kernel<1>, gridt, block, 0, st, a);
+    else hipLaunchKernelGGL(tiny4_kernel<2>, gridt, block, 0, st, a);
+    SSG_LAUNCH_CHECK();
+    return SSG_OK;
+  }
+  if (routes_thin32(d, kind)) {
+    a.strips = (d->W + 31) / 32;
+    a.ybands = (d->H + RH_K36 - 1) / RH_K36;
+    a.total_units = d->N * a.ybands * a.strips;
+    int wpg2 = 8192 / a.groups;
+    if (wpg2 > a.total_units) wpg2 = a.total_units;
+    a.waves_per_group = wpg2;
+    const dim3 grid2((unsigned)((wpg2 * a.groups + 3) / 4));
+    static const int nt32 = [] { const char* e = getenv("SSG_THIN32_NT"); return e ? atoi(e) : 1; }();
+    const bool nt = nt32 && a.nt_store;
+    if (d->res) {
+      if (nt) hipLaunchKernelGGL((thin32_cin_kernel<true, 1, true>), grid2, block, 0, st, a);
+      else hipLaunchKernelGGL((thin32_cin_kernel<true, 1, false>), grid2, block, 0, st, a);
+    } else {
+      if (nt) hipLaunchKernelGGL((thin32_cin_kernel<false, 1, true>), grid2, block, 0, st, a);
+      else hipLaunchKernelGGL((thin32_cin_kernel<false, 1, false>), grid2, block, 0, st, a);
+    }
+    SSG_LAUNCH_CHECK();
+    return SSG_OK;
+  }
   if (kind == 3) {
     static const int pf = [] { const char* e = getenv("SSG_THIN4_PF"); return e ? atoi(e) : 2; }();     // rows in flight (A/B switch)
     if (d->res) {

@@ -121,9 +121,57 @@ __global__ __launch_bounds__(256) void wgrad4_kernel(const W4Args a) {
   }
 }
 
+// ------------------------------------------------------------------ tiny: in has 4 channels AND dout has <= 8 (SPADE's 3 -> nhidden
+// conv, normalization.py:92).  VALU: thread (pixel slot k = tid / 8, output channel co = tid % 8) walks the workgroup's pixel
+// range with stride 32, 36 accumulators dw[co][tap][c]; the 9 window loads are shared by the 8 channel threads of a pixel
+// (same address).  The 32 pixel slots are folded through LDS in slot order, one slab per workgroup, ordered reduce after.
+constexpr int TINY_PIX = 4096;        // pixels per workgroup
+
+__global__ __launch_bounds__(256) void wgrad_tiny4_kernel(const W4Args a) {
+  const int co = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const long long npix = (long long)a.N * a.H * a.W;
+  const long long p0 = (long long)blockIdx.x * TINY_PIX;
+  const long long p1 = p0 + TINY_PIX < npix ? p0 + TINY_PIX : npix;
+  const auto in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.thin), 0, (int)((unsigned)npix * (unsigned)a.ldt * 4u), 0x00020000);
+  const auto do_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wide), 0, (int)((unsigned)npix * (unsigned)a.ldw * 4u), 0x00020000);
+  constexpr unsigned OOB = 0xffffffffu;
+  const bool co_ok = co < a.Cout;
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long long p = p0 + slot; p < p1; p += 32) {
+    const int x = (int)(p % a.W); const int y = (int)((p / a.W) % a.H);
+    const float g = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(do_rs, co_ok ? ((unsigned)p * (unsigned)a.ldw + (unsigned)co) * 4u : OOB, 0, 0));
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          in_rs, ok ? (unsigned)(p + (long long)(t / 3 - 1) * a.W + (t % 3 - 1)) * (unsigned)a.ldt * 4u : OOB, 0, 0));
+      acc[t] += v * g;
+    }
+  }
+  __shared__ float red[32][36][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[slot][t * 4 + c][co] = acc[t][c];
+  __syncthreads();
+  // slab layout of conv_wgrad.hip: [slab][row = t*Cin + c][Cout]
+  float* slab = a.ws + (size_t)blockIdx.x * 9 * a.Cin * a.Cout;
+  for (int e = threadIdx.x; e < 36 * 8; e += 256) {
+    const int c8 = e & 7, row = e >> 3;
+    float sum = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) sum += red[k][row][c8];
+    const int t = row >> 2, c = row & 3;
+    if (c8 < a.Cout && c < a.Cin) slab[((size_t)t * a.Cin + c) * a.Cout + c8] = sum;
+  }
+}
+
 }  // namespace
 
-// kind 5: dout thin (Cout <= 4), kind 6: in thin (Cin_pad == 4)
+// kind 5: dout thin (Cout <= 4), kind 6: in thin (Cin_pad == 4), kind 7: both (Cin_pad == 4, Cout <= 8; VALU)
 int ssg_wgrad4_kind(const ssg_wgrad_desc* d) {
   if (d->C2 != 0 || d->in_sy != 1 || d->in_sx != 1 || d->GH != d->H || d->GW != d->W) return 0;
   if (d->ntaps == 9) {
@@ -134,11 +182,19 @@ int ssg_wgrad4_kind(const ssg_wgrad_desc* d) {
   // 32-bit byte offsets (buffer descriptors) inside the kernel
   if ((long long)d->N * d->H * d->W * (d->ld1 > d->ldd ? d->ld1 : d->ldd) >= (1ll << 30)) return 0;
   if (d->Cout <= 4 && d->C1 >= 16 && d->C1 % 4 == 0) return 5;
+  static const int tiny = [] { const char* e = getenv("SSG_TINY4"); return e ? atoi(e) : 1; }();
+  if (tiny && d->C1 == 4 && d->Cout <= 8 && d->ntaps == 9) return 7;
   if (d->C1 == 4) return 6;
   return 0;
 }
 
 int ssg_wgrad4_slices(const ssg_wgrad_desc* d, int kind, int* groups, long long* units_per_z, int* segs_per_row) {
+  if (kind == 7) {
+    if (groups) *groups = 1;
+    if (units_per_z) *units_per_z = TINY_PIX;
+    if (segs_per_row) *segs_per_row = 1;
+    return (int)(((long long)d->N * d->H * d->W + TINY_PIX - 1) / TINY_PIX);
+  }
   const int cw = kind == 5 ? d->C1 : d->Cout;
   const int g = (cw + 63) / 64;
   const int spr = (d->W + SEG - 1) / SEG;
@@ -160,6 +216,12 @@ int ssg_wgrad4_launch(const ssg_wgrad_desc* d, int kind, hipStream_t st) {
   a.ws = d->ws; a.N = d->N; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Cin = d->C1;
   a.nz = ssg_wgrad4_slices(d, kind, &a.groups, &a.units_per_z, &a.segs_per_row);
   const dim3 grid((unsigned)(a.nz * a.groups)), block(256);
+  if (kind == 7) {
+    a.wide = d->dout; a.Cw = d->Cout; a.ldw = d->ldd; a.thin = d->in1; a.ldt = d->ld1;
+    hipLaunchKernelGGL(wgrad_tiny4_kernel, grid, block, 0, st, a);
+    SSG_LAUNCH_CHECK();
+    return SSG_OK;
+  }
   if (kind == 5) { a.wide = d->in1; a.Cw = d->C1; a.ldw = d->ld1; a.thin = d->dout; a.ldt = d->ldd; }
   else { a.wide = d->dout; a.Cw = d->Cout; a.ldw = d->ldd; a.thin = d->in1; a.ldt = d->ld1; }
   if (kind == 5 && d->ntaps == 9) hipLaunchKernelGGL((wgrad4_kernel<true, 3>), grid, block, 0, st, a);

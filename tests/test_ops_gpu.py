@@ -66,6 +66,11 @@ def test_conv2d_fwd_bwd(pkg, dev, case):
 KERNEL_CASES = [
     # n, cin, cout, h, w, k, pad, kernels that must have run (forward, input gradient, weight gradient)
     (2, 3, 64, 37, 45, 3, 1, ('thin4_cin_kernel', 'thin4_cout_kernel', 'wgrad4_kernel<thin_cin>')),
+    (2, 3, 64, 150, 237, 3, 1, ('thin32_cin_kernel', 'thin4_cout_kernel', 'wgrad4_kernel<thin_cin>')),   # >= 65536 pixels: 32-pixel strips
+    (1, 4, 96, 260, 270, 3, 1, ('thin32_cin_kernel',)),                    # two 64-channel groups, the second half empty; full + edge strips
+    (2, 3, 4, 37, 45, 3, 1, ('tiny4_kernel', 'wgrad_tiny4_kernel')),       # 4 -> <= 8 channels: VALU kernels
+    (1, 4, 7, 19, 70, 3, 1, ('tiny4_kernel', 'wgrad_tiny4_kernel')),
+    (2, 3, 64, 16, 20, 1, 0, ('thin4_cin_kernel',)),                       # 1x1 with a 4-channel input stays on the 4x4x1 kernel
     (1, 128, 4, 19, 23, 3, 1, ('thin4_cout_kernel', 'thin4_cin_kernel', 'wgrad4_kernel<thin_cout>')),
     (2, 64, 1, 16, 20, 1, 0, ('thin4_cout_kernel', 'thin4_cin_kernel', 'wgrad4_kernel<thin_cout>')),
     (2, 128, 7, 21, 30, 3, 1, ('thin4_cout_kernel',)),                     # Cout 5..8: two output-channel groups
@@ -119,6 +124,28 @@ def test_conv2d_specialised_kernels(pkg, dev, case):
     _close(d[1].grad, ref[1].grad, 2e-5, 2e-6 * math.sqrt(n * h * w), 'wgrad')
     _close(d[2].grad, ref[2].grad, 2e-5, 1e-5, 'bias grad')
     _close(d[3].grad, ref[3].grad, 1e-6, 1e-6, 'residual grad')
+
+
+@pytest.mark.parametrize('act', ['relu', 'lrelu'])
+def test_thin32_forward_with_activation(pkg, dev, act):
+    """The 32x32x2-MFMA thin-Cin kernel with bias + residual + activation (forward only: continuous in the pre-activation, so
+    no mask flips at this size; its gradients are covered without activation in KERNEL_CASES)."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 3, 256, 257, generator=g); wt = torch.randn(40, 3, 3, 3, generator=g) / 5.2
+    b = torch.randn(40, generator=g); rs = torch.randn(1, 40, 256, 257, generator=g)
+    yr = F.conv2d(x, wt, b, 1, 1) + rs
+    yr = F.relu(yr) if act == 'relu' else F.leaky_relu(yr, 0.2)
+    pkg.ops.PROFILE = []
+    try:
+        yd = pkg.ops.conv2d(x.to(dev), wt.to(dev), b.to(dev), 1, 1, act=pkg._lib.ACT_RELU if act == 'relu' else pkg._lib.ACT_LRELU,
+                            slope=0.2, res=rs.to(dev))
+        labels = [rec[0] for rec in pkg.ops.PROFILE]
+    finally:
+        pkg.ops.PROFILE = None
+    assert labels == ['thin32_cin_kernel'], labels
+    _close(yd, yr, 1e-5, 2e-6 * math.sqrt(27), 'thin32 fwd + act')
+    yd2 = pkg.ops.conv2d(x.to(dev), wt.to(dev), None, 1, 1, act=pkg._lib.ACT_RELU)          # no residual: the other instantiation
+    _close(yd2, F.relu(F.conv2d(x, wt, None, 1, 1)), 1e-5, 2e-6 * math.sqrt(27), 'thin32 fwd relu')
 
 
 def _random_conv_cases(count=28, seed=2024):
