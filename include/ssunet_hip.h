@@ -156,6 +156,9 @@ int ssg_pixel_gate_bwd_f32(const float* x, int ldx, const float* g, int ldg, con
 int64_t ssg_linear_fwd_workspace_bytes(int n, int k, int o);
 int ssg_linear_fwd_f32(const float* x, int n, int k, int ldx, const float* w, int o, const float* bias, int act,
                        float slope, float* y, int ldy, float* ws, int64_t ws_bytes, void* stream);
+/* dw[o][k] = sum_n dy[n][o] * x[n][k] (the weight gradient of nn.Linear, models_seg_gan.py:281-283), contiguous [O][K] output,
+ * summed over n in order; x rows of stride ldx (k % 4 == 0, 16-byte aligned), dy rows of stride ldd. */
+int ssg_linear_wgrad_f32(const float* x, int n, int k, int ldx, const float* dy, int o, int ldd, float* dw, void* stream);
 
 /* ------------------------------------------------------------------ bf16 pointwise convolution (BASELINE config 4)
  * SURVEY.md 8(b) `conv2d_{fwd,dgrad,wgrad}_nhwc_bf16` for the 1x1 layers of the EfficientNet MBConv blocks

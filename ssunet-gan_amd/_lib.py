@@ -126,6 +126,7 @@ SIGNATURES = {
     'ssg_pixel_gate_bwd_f32': [_P, _I, _P, _I, _P, _I, _L, _I, _P, _I, _P, _I, _P],
     'ssg_linear_fwd_workspace_bytes': [_I, _I, _I],
     'ssg_linear_fwd_f32': [_P, _I, _I, _I, _P, _I, _P, _I, _F, _P, _I, _P, _L, _P],
+    'ssg_linear_wgrad_f32': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
     'ssg_pack_weights_bf16': [_P, _I, _I, _I, _I, _I, _P, _P],
     'ssg_gemm_bf16': [_P, _L, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P],
     'ssg_gemm_wgrad_bf16_workspace_bytes': [_L, _I, _I],

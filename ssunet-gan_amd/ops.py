@@ -469,7 +469,11 @@ class _Linear(torch.autograd.Function):
             d = _conv_dgrad_impl(dy, w4, 1, 0, 1, n, 0, k)
             dx = d.as_strided((n, k), (_ld(d), 1))
         if ctx.needs_input_grad[1]:
-            dw = _conv_wgrad_impl(xi, None, dy, (o, k, 1, 1), 1, 0).view(o, k)
+            if k % 4 == 0 and xi.data_ptr() % 16 == 0 and xi.stride(3) % 4 == 0:
+                dw = torch.empty((o, k), device=dy.device, dtype=torch.float32)
+                call('ssg_linear_wgrad_f32', ptr(xi), n, k, xi.stride(3), ptr(dy), o, dy.stride(3), ptr(dw), stream_ptr())
+            else:
+                dw = _conv_wgrad_impl(xi, None, dy, (o, k, 1, 1), 1, 0).view(o, k)
         if has_bias and ctx.needs_input_grad[2]:
             db = _channel_sum(dy, o)
         return dx, dw, db, None, None
