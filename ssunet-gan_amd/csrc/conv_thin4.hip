@@ -15,7 +15,8 @@
 #include "common.h"
 #include "conv_thin.h"
 #ifndef SSG_T4_EXP
-#define SSG_T4_EXP 0      // 1 = no MFMAs, 2 = no output stores: ablation builds of thin4_cin (tools/micro_thin_exp.py), never shipped
+#define SSG_T4_EXP 0      // 1 = no MFMAs, 2 = no output stores: ablation builds of thin4_cin; 3 = no MFMAs, 4 = cache-resident loads:
+                          // of thin4_cout (tools/micro_thin_exp.py), never shipped
 #endif
 #include <stdlib.h>
 
@@ -430,8 +431,13 @@ __global__ __launch_bounds__(256) void thin4_cout_kernel(const T4Args a) {
       auto load_row = [&](f32x4* dst, int iy) {
         const bool rok = (unsigned)iy < (unsigned)a.H;
         const unsigned ro = imgoff + (unsigned)iy * (unsigned)a.W * ldb + (unsigned)ch * 256u;
+#if SSG_T4_EXP == 4                                        // ablation: every row load reads the same cache-resident 1 KiB
+#pragma unroll
+        for (int e = 0; e < KS; ++e) dst[e] = ldbuf4(in_rs, (rok && coloff[e] != OOB) ? (unsigned)(lane * 16) : OOB);
+#else
 #pragma unroll
         for (int e = 0; e < KS; ++e) dst[e] = ldbuf4(in_rs, (rok && coloff[e] != OOB) ? ro + coloff[e] : OOB);
+#endif
       };
       f32x4 v[RING][KS];
 #pragma unroll
@@ -446,8 +452,13 @@ __global__ __launch_bounds__(256) void thin4_cout_kernel(const T4Args a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-              for (int g = 0; g < NG; ++g)
+              for (int g = 0; g < NG; ++g) {
+#if SSG_T4_EXP == 3                                        // ablation: no MFMAs (loaded rows stay live through one add per value)
+                accg[g][s][c] += v[(s + q) % RING][e][c];
+#else
                 accg[g][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][q * KS + e][c], v[(s + q) % RING][e][c], accg[g][s], 0, 0, 0);
+#endif
+              }
       }
     }
 #pragma unroll
