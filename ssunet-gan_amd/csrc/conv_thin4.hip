@@ -376,6 +376,72 @@ __global__ __launch_bounds__(256) void tiny4_kernel(const T4Args a) {
   }
 }
 
+// Fold the 16 K-blocks of one output-channel group (8 rows x 4 pixels x 4 channels per lane) and store: lane bit 5 (b bit 3)
+// halves the rows 8 -> 4, bit 4: 4 -> 2, bit 3: 2 -> 1, bit 2 (b bit 0) halves the 4 channels -> 2; the kept half is chosen
+// by the lane's own bit, so the order of the additions is fixed.
+__device__ __forceinline__ void t4_fold_store(const T4Args& a, const f32x4* acc, int lane, int g, int n, int x, int y0, int my_s, int my_c,
+                                              float bias0g, float bias1g) {
+    // fold the 16 K-blocks: lane bit 5 (b bit 3) halves the rows 8 -> 4, bit 4: 4 -> 2, bit 3: 2 -> 1,
+    // bit 2 (b bit 0) halves the 4 channels -> 2.  Kept half is chosen by the lane's own bit.
+    float h4[4][4];
+    {
+      const bool hi = (lane >> 5) & 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float keep = hi ? acc[s + 4][i] : acc[s][i];
+          const float send = hi ? acc[s][i] : acc[s + 4][i];
+          h4[s][i] = keep + __shfl_xor(send, 32);
+        }
+    }
+    float h2[2][4];
+    {
+      const bool hi = (lane >> 4) & 1;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float keep = hi ? h4[s + 2][i] : h4[s][i];
+          const float send = hi ? h4[s][i] : h4[s + 2][i];
+          h2[s][i] = keep + __shfl_xor(send, 16);
+        }
+    }
+    float h1[4];
+    {
+      const bool hi = (lane >> 3) & 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float keep = hi ? h2[1][i] : h2[0][i];
+        const float send = hi ? h2[0][i] : h2[1][i];
+        h1[i] = keep + __shfl_xor(send, 8);
+      }
+    }
+    float o0, o1;
+    {
+      const bool hi = (lane >> 2) & 1;
+      const float k0 = hi ? h1[2] : h1[0], k1 = hi ? h1[3] : h1[1];
+      const float s0 = hi ? h1[0] : h1[2], s1 = hi ? h1[1] : h1[3];
+      o0 = k0 + __shfl_xor(s0, 4);
+      o1 = k1 + __shfl_xor(s1, 4);
+    }
+    // lane bits: bit5 -> s bit 2, bit4 -> s bit 1, bit3 -> s bit 0, bit2 -> channel pair  == (b >> 1, b & 1)
+    const int y = y0 + my_s;
+    if (x < a.W && y < a.H) {
+      const size_t pix = (size_t)(n * a.H + y) * a.W + x;
+      const int ch = 4 * g + my_c;
+      float t0 = o0 + bias0g, t1 = o1 + bias1g;
+      if (a.res) {
+        if (ch < a.Cout) t0 += a.res[pix * a.ldr + ch];
+        if (ch + 1 < a.Cout) t1 += a.res[pix * a.ldr + ch + 1];
+      }
+      float2 o;
+      o.x = ch < a.Cout ? act_apply(t0, a.act, a.slope) : 0.f;
+      o.y = ch + 1 < a.Cout ? act_apply(t1, a.act, a.slope) : 0.f;
+      if (ch < ((a.Cout + 3) & ~3)) *(float2*)(a.out + pix * a.ldo + ch) = o;
+    }
+}
+
 // ------------------------------------------------------------------ thin-Cout: Cout <= 4*NG, C % 64 == 0
 // NG = 2 (Cout 5..8, e.g. the 128 -> 8 gamma/beta input gradients) runs two A-operand sets over the same loaded rows.
 template <int KS, int NG>
@@ -434,6 +500,9 @@ __global__ __launch_bounds__(256) void thin4_cout_kernel(const T4Args a) {
 #if SSG_T4_EXP == 4                                        // ablation: every row load reads the same cache-resident 1 KiB
 #pragma unroll
         for (int e = 0; e < KS; ++e) dst[e] = ldbuf4(in_rs, (rok && coloff[e] != OOB) ? (unsigned)(lane * 16) : OOB);
+#elif SSG_T4_EXP == 5                                      // ablation: only the dx = 0 load is real, dx = +-1 read that KiB
+#pragma unroll
+        for (int e = 0; e < KS; ++e) dst[e] = ldbuf4(in_rs, (rok && coloff[e] != OOB) ? (e == R ? ro + coloff[e] : (unsigned)(lane * 16)) : OOB);
 #else
 #pragma unroll
         for (int e = 0; e < KS; ++e) dst[e] = ldbuf4(in_rs, (rok && coloff[e] != OOB) ? ro + coloff[e] : OOB);
@@ -462,70 +531,14 @@ __global__ __launch_bounds__(256) void thin4_cout_kernel(const T4Args a) {
       }
     }
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-    f32x4* acc = accg[g];
-    // fold the 16 K-blocks: lane bit 5 (b bit 3) halves the rows 8 -> 4, bit 4: 4 -> 2, bit 3: 2 -> 1,
-    // bit 2 (b bit 0) halves the 4 channels -> 2.  Kept half is chosen by the lane's own bit.
-    float h4[4][4];
-    {
-      const bool hi = (lane >> 5) & 1;
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float keep = hi ? acc[s + 4][i] : acc[s][i];
-          const float send = hi ? acc[s][i] : acc[s + 4][i];
-          h4[s][i] = keep + __shfl_xor(send, 32);
-        }
-    }
-    float h2[2][4];
-    {
-      const bool hi = (lane >> 4) & 1;
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float keep = hi ? h4[s + 2][i] : h4[s][i];
-          const float send = hi ? h4[s][i] : h4[s + 2][i];
-          h2[s][i] = keep + __shfl_xor(send, 16);
-        }
-    }
-    float h1[4];
-    {
-      const bool hi = (lane >> 3) & 1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float keep = hi ? h2[1][i] : h2[0][i];
-        const float send = hi ? h2[0][i] : h2[1][i];
-        h1[i] = keep + __shfl_xor(send, 8);
-      }
-    }
-    float o0, o1;
-    {
-      const bool hi = (lane >> 2) & 1;
-      const float k0 = hi ? h1[2] : h1[0], k1 = hi ? h1[3] : h1[1];
-      const float s0 = hi ? h1[0] : h1[2], s1 = hi ? h1[1] : h1[3];
-      o0 = k0 + __shfl_xor(s0, 4);
-      o1 = k1 + __shfl_xor(s1, 4);
-    }
-    // lane bits: bit5 -> s bit 2, bit4 -> s bit 1, bit3 -> s bit 0, bit2 -> channel pair  == (b >> 1, b & 1)
-    const int y = y0 + my_s;
-    if (x < a.W && y < a.H) {
-      const size_t pix = (size_t)(n * a.H + y) * a.W + x;
-      const int ch = 4 * g + my_c;
-      float t0 = o0 + bias0[g], t1 = o1 + bias1[g];
-      if (a.res) {
-        if (ch < a.Cout) t0 += a.res[pix * a.ldr + ch];
-        if (ch + 1 < a.Cout) t1 += a.res[pix * a.ldr + ch + 1];
-      }
-      float2 o;
-      o.x = ch < a.Cout ? act_apply(t0, a.act, a.slope) : 0.f;
-      o.y = ch + 1 < a.Cout ? act_apply(t1, a.act, a.slope) : 0.f;
-      if (ch < ((a.Cout + 3) & ~3)) *(float2*)(a.out + pix * a.ldo + ch) = o;
-    }
-    }
+    for (int g = 0; g < NG; ++g) t4_fold_store(a, accg[g], lane, g, n, x, y0, my_s, my_c, bias0[g], bias1[g]);
   }
 }
+
+// (A streaming form of this kernel -- a wave walking a column of bands with all 10 rows of a body in a register ring, every row
+//  requested a whole body before its first use -- was built and measured in round 2: 0.580 vs 0.585 ms at 16 x 512^2, 64 -> 3.
+//  Ablations (tools/micro_thin_cout.py): no MFMAs 0.520, every load from one cache-resident KiB 0.319, only the dx = 0 loads
+//  real 0.480: the time is issue (0.32) PLUS memory (0.16 unique + 0.10 for the overlapping dx loads), not latency.)
 
 bool window_taps(const ssg_conv_desc* d, int* tapidx) {
   for (int p = 0; p < 9; ++p) tapidx[p] = -1;
