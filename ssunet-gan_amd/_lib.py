@@ -155,6 +155,8 @@ _RESTYPES = {
 }
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id'}
 
+ABI_VERSION = 3          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
+
 _lib = None
 
 
@@ -174,6 +176,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = _RESTYPES.get(name, C.c_int)
+    got = lib.ssg_abi_version()
+    if got != ABI_VERSION:                # a stale .so with another descriptor layout would corrupt memory, not just fail
+        raise HipLibraryError('%s reports ABI version %d, this package was written against %d: rebuild it '
+                              '(`make -C ssunet-gan_amd/csrc`)' % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 
