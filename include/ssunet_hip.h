@@ -278,11 +278,20 @@ int ssg_adaptive_avgpool_flat_bwd_f32(const float* dy, int N, int H, int W, int 
  * SPADE modulate out = x*(1+gamma)+beta (normalization.py:120) and its gradients
  * dx = dy*(1+gamma), dgamma = dy*x, dbeta = dy.  gb holds gamma in channels [0,C) and beta
  * in [C,2C) of one 2C-channel tensor (the fused gamma|beta conv output). */
+/* SPADE with the gamma|beta conv and the modulation in ONE kernel (normalization.py:117-120): `d` describes the 3x3 conv from the
+ * 4-channel (padded) activation to 2C channels whose packed weight rows are [gamma 0..C-1 | beta C..2C-1] (bias likewise, no
+ * residual / activation), but d->out receives  x * (1 + gamma) + beta  (C channels, pixel stride d->ldo) and `gamma` (incl. its
+ * bias; pixel stride ldg) is kept for the backward pass; the [N,2C,H,W] tensor never exists.  ssg_spade_conv_modulate_ok(d):
+ * 1 when this shape runs on the fused kernel (4-channel input, 3x3, >= 65536 pixels), else the caller runs ssg_conv2d_f32 +
+ * ssg_spade_modulate_fwd_f32. */
+int ssg_spade_conv_modulate_ok(const ssg_conv_desc* d);
+int ssg_spade_conv_modulate_f32(const ssg_conv_desc* d, const float* x, int ldx, float* gamma, int ldg, void* stream);
 int ssg_spade_modulate_fwd_f32(const float* x, int ldx, const float* gb, int ldgb, int64_t P, int C, float* y, int ldy, void* stream);
 int ssg_spade_modulate_bwd_f32(const float* x, int ldx, const float* gb, int ldgb, const float* dy, int lddy, int64_t P, int C,
                                float* dx, int lddx, float* dgb, int lddgb, void* stream);
 /* the same pass that also returns the bias gradients of the gamma / beta convs (normalization.py:94-96):
- * sums[0:C] = sum_p dy*x, sums[C:2C] = sum_p dy, fp64, deterministic; ws: ssg_bn_workspace_bytes(P, C) bytes */
+ * sums[0:C] = sum_p dy*x, sums[C:2C] = sum_p dy, fp64, deterministic; ws: ssg_bn_workspace_bytes(P, C) bytes.  Only the gamma
+ * half of `gb` is read (ldgb >= C: a gamma-only tensor from ssg_spade_conv_modulate_f32 is fine). */
 int ssg_spade_modulate_bwd_sums_f32(const float* x, int ldx, const float* gb, int ldgb, const float* dy, int lddy, int64_t P,
                                     int C, float* dx, int lddx, float* dgb, int lddgb, double* sums, void* ws, void* stream);
 /* activation backward: dx = dy * (y > 0 ? 1 : slope) (+ add) */

@@ -90,6 +90,8 @@ SIGNATURES = {
     'ssg_upsample2x_nearest_bwd_f32': [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     'ssg_adaptive_avgpool_flat_fwd_f32': [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     'ssg_adaptive_avgpool_flat_bwd_f32': [_P, _I, _I, _I, _I, _I, _P, _I, _P],
+    'ssg_spade_conv_modulate_ok': [C.POINTER(ConvDesc)],
+    'ssg_spade_conv_modulate_f32': [C.POINTER(ConvDesc), _P, _I, _P, _I, _P],
     'ssg_spade_modulate_fwd_f32': [_P, _I, _P, _I, _L, _I, _P, _I, _P],
     'ssg_spade_modulate_bwd_f32': [_P, _I, _P, _I, _P, _I, _L, _I, _P, _I, _P, _I, _P],
     'ssg_spade_modulate_bwd_sums_f32': [_P, _I, _P, _I, _P, _I, _L, _I, _P, _I, _P, _I, _P, _P, _P],
@@ -153,7 +155,8 @@ _RESTYPES = {
     'ssg_gemm_wgrad_bf16_workspace_bytes': C.c_int64,
     'ssg_bn_stats_from_partials_workspace_bytes': C.c_int64,
 }
-_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id'}
+_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
+                                'ssg_spade_conv_modulate_ok'}
 
 ABI_VERSION = 3          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
 

@@ -96,6 +96,36 @@ def _spade_cat(wg, bg, wb, bb):
     return w, b
 
 
+def _spade_fused_fwd(x, a, wgb, bgb, pad, out):
+    """gamma|beta conv + modulation in one kernel (ssg_spade_conv_modulate_f32) where the shape allows it (4-channel `a`, 3x3,
+    >= 65536 pixels: the 512^2 level at batch 16).  Writes `out`, returns gamma (needed by the backward) or None."""
+    o, i, kh, kw = wgb.shape
+    n, c, h, w = x.shape
+    if kh != 3 or kw != 3 or pad != 1 or ops.pad4(a.shape[1]) != 4 or o != 2 * c or c % 4:
+        return None
+    from ._lib import ConvDesc
+    import ctypes as C
+    taps = ops._taps_fwd(kh, kw, pad)
+    wpk, kp, kmode = ops._pack(wgb, 0, taps, 4, 4)
+    d = ConvDesc()
+    d.in1 = a.data_ptr(); d.C1 = 4; d.ld1 = _ld(a); d.in2 = None; d.C2 = 0; d.ld2 = 0
+    d.N, d.H, d.W = n, h, w
+    d.w = wpk.data_ptr(); d.Kp = kp; d.kmode = kmode
+    d.bias = bgb.data_ptr(); d.res = None; d.ldr = 0
+    d.out = out.data_ptr(); d.Cout = o; d.ldo = _ld(out)
+    d.GH, d.GW, d.OH, d.OW = h, w, h, w
+    d.in_sy = d.in_sx = d.out_sy = d.out_sx = 1
+    d.out_oy = d.out_ox = 0
+    ops._fill_taps(d, taps)
+    d.act = ACT_NONE; d.slope = 0.0; d.bnpart = None; d.ws = None; d.ws_bytes = 0
+    if not call('ssg_spade_conv_modulate_ok', C.byref(d)):
+        return None
+    gamma = new_nhwc(n, c, h, w, x.device)
+    with ops._Timed('thin32_cin_kernel<spade>' if ops.PROFILE is not None else None, 2.0 * n * h * w * o * a.shape[1] * 9):
+        call('ssg_spade_conv_modulate_f32', C.byref(d), ptr(x), _ld(x), ptr(gamma), _ld(gamma), stream_ptr())
+    return gamma
+
+
 class _SpadeFn(torch.autograd.Function):
     """Self-conditioned SPADE: out = x*(1+gamma(a)) + beta(a), a = relu(shared(x2map(x))).
     gamma and beta come from one conv nhidden -> 2C (concatenated weights) writing gamma|beta pixel rows; its input
@@ -108,9 +138,11 @@ class _SpadeFn(torch.autograd.Function):
         seg = _conv_fwd_impl(x, None, wx, bx, 1, pad, ACT_NONE, 0.0)
         a = _conv_fwd_impl(seg, None, ws, bs, 1, pad, ACT_RELU, 0.0)
         wgb, bgb = _spade_cat(wg, bg, wb, bb)
-        gb = _conv_fwd_impl(a, None, wgb, bgb, 1, pad, ACT_NONE, 0.0)
         out = new_nhwc(n, c, h, w, x.device)
-        call('ssg_spade_modulate_fwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), n * h * w, c, ptr(out), _ld(out), stream_ptr())
+        gb = _spade_fused_fwd(x, a, wgb, bgb, pad, out)           # gamma only ([n, c, h, w]) when the fused kernel took it
+        if gb is None:
+            gb = _conv_fwd_impl(a, None, wgb, bgb, 1, pad, ACT_NONE, 0.0)
+            call('ssg_spade_modulate_fwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), n * h * w, c, ptr(out), _ld(out), stream_ptr())
         ctx.save_for_backward(x, seg, a, gb, wx, ws, wgb)
         ctx.pad = pad
         return out

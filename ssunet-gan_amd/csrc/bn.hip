@@ -522,7 +522,7 @@ extern "C" int ssg_bn_bwd_apply_bf16(const void* x, const void* y, const void* d
 
 extern "C" int ssg_spade_modulate_bwd_sums_f32(const float* x, int ldx, const float* gb, int ldgb, const float* dy, int lddy, int64_t P,
                                                int C, float* dx, int lddx, float* dgb, int lddgb, double* sums, void* ws, void* stream) {
-  SSG_REQUIRE(x && gb && dy && dx && dgb && sums && ws && P > 0 && C > 0 && C % 4 == 0 && ldgb >= 2 * C && lddgb >= 2 * C, SSG_EINVAL,
+  SSG_REQUIRE(x && gb && dy && dx && dgb && sums && ws && P > 0 && C > 0 && C % 4 == 0 && ldgb >= C && lddgb >= 2 * C, SSG_EINVAL,
               "modulate_bwd_sums: bad args");
   const RedGeom g = red_geom(P, C);
   double* part = (double*)ws;

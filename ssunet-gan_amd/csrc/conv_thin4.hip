@@ -29,6 +29,7 @@ struct T4Args {
   int act; float slope;
   int groups, waves_per_group, total_units, strips, ybands;
   int nt_store;              // thin-Cin: non-temporal output stores (output larger than the caches)
+  float* gsave; int ldg;     // thin32 SPADE mode: where gamma (+ bias) goes (the backward needs it), pixel stride
 };
 
 constexpr int RH_CIN = 16;       // rows per work unit (thin-Cin): a 4-pixel-wide strip marched downwards
@@ -187,8 +188,13 @@ __device__ __forceinline__ f32x2 ldbuf2(__amdgpu_buffer_rsrc_t rs, unsigned off)
 
 constexpr int RH_K36 = 16;       // output rows per work unit
 
-template <bool HAS_RES, int PF, bool NT>
+// MODE 0: out = act(conv + bias); 1: + residual; 2: SPADE (normalization.py:117-120) -- `w` holds [gamma rows 0..C-1 | beta rows
+// C..2C-1] (a.Cout = 2C), the wave's two N-fragments are gamma and beta of the SAME 32 channels, `res` is the tensor being
+// modulated: out = x * (1 + gamma) + beta, and gamma goes to a.gsave.  The [N,2C,H,W] gamma|beta tensor and the separate
+// modulate pass (3 reads + 1 write of C channels) never exist.
+template <int MODE, int PF, bool NT>
 __global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
+  constexpr bool HAS_RES = MODE >= 1, SPADE = MODE == 2;
   constexpr int AUX = NT ? 2 : 0;           // non-temporal stores for outputs far larger than the caches
   constexpr int RING = 3 + PF;
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
@@ -200,14 +206,18 @@ __global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
   const auto out_rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(npix * (unsigned)a.ldo * 4u), 0x00020000);
   const auto res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_RES ? a.res : a.in), 0,
                                                         (int)(npix * (unsigned)(HAS_RES ? a.ldr : a.ld) * 4u), 0x00020000);
-  const unsigned ldb = (unsigned)a.ld * 4u, ldob = (unsigned)a.ldo * 4u, ldrb = (unsigned)a.ldr * 4u;
+  const auto g_rs = __builtin_amdgcn_make_buffer_rsrc(SPADE ? a.gsave : a.out, 0, (int)(npix * (unsigned)(SPADE ? a.ldg : a.ldo) * 4u), 0x00020000);
+  const unsigned ldb = (unsigned)a.ld * 4u, ldob = (unsigned)a.ldo * 4u, ldrb = (unsigned)a.ldr * 4u, ldgb = (unsigned)a.ldg * 4u;
+  const int Cmod = a.Cout >> 1;            // SPADE: channels of x / out / gamma
 
   // B operand: K-step s = 2*p + j (p = window position, j = channel of the lane half's pair) for the lane's output channel
   float wB[2][18], bv[2], keep[2];       // keep = 0 for the pad lanes [Cout, pad4(Cout)): written as 0
   unsigned vo_out[2], vo_res[2];         // per-lane part of the byte offset (pixel 4*h of the strip, this lane's channel) or OOB
+  unsigned vo_g = OOB;
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    const int co = cg * 64 + f * 32 + l31;
+    const int cm = cg * 32 + l31;          // SPADE: the modulated channel of this lane
+    const int co = SPADE ? (cm < Cmod ? f * Cmod + cm : a.Cout) : cg * 64 + f * 32 + l31;
 #pragma unroll
     for (int p = 0; p < 9; ++p) {
       const int t = a.tapidx[p];
@@ -217,9 +227,11 @@ __global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
     }
     bv[f] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
     keep[f] = co < a.Cout ? 1.f : 0.f;
-    const bool cok = co < ((a.Cout + 3) & ~3);
-    vo_out[f] = cok ? 4u * (unsigned)h * ldob + (unsigned)co * 4u : OOB;
-    vo_res[f] = cok ? 4u * (unsigned)h * ldrb + (unsigned)co * 4u : OOB;
+    const bool cok = SPADE ? cm < Cmod : co < ((a.Cout + 3) & ~3);
+    const int cch = SPADE ? cm : co;       // channel inside out / res rows
+    vo_out[f] = cok ? 4u * (unsigned)h * ldob + (unsigned)cch * 4u : OOB;
+    vo_res[f] = cok ? 4u * (unsigned)h * ldrb + (unsigned)cch * 4u : OOB;
+    if (SPADE) vo_g = cok ? 4u * (unsigned)h * ldgb + (unsigned)cch * 4u : OOB;
   }
   const bool is_relu = a.act == SSG_ACT_RELU;
   const float neg_slope = a.act == SSG_ACT_LRELU ? a.slope : 1.f;
@@ -272,11 +284,21 @@ __global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
       const unsigned (&vo)[2] = vo_out; const unsigned (&vr)[2] = vo_res;
       if (HAS_RES) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < (SPADE ? 1 : 2); ++f)
 #pragma unroll
           for (int q = 0; q < 16; ++q)
             rv[f][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                 res_rs, vr[f], (int)((rowpix + (unsigned)((q & 3) + 8 * (q >> 2))) * ldrb), 0));
+      }
+      if (SPADE) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float g = acc[0][q] + bv[0], bt = acc[1][q] + bv[1];
+          const unsigned pq = rowpix + (unsigned)((q & 3) + 8 * (q >> 2));
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), g_rs, vo_g, (int)(pq * ldgb), AUX);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaf(rv[0][q], 1.f + g, bt)), out_rs, vo[0], (int)(pq * ldob), AUX);
+        }
+        return;
       }
 #pragma unroll
       for (int f = 0; f < 2; ++f)
@@ -292,6 +314,19 @@ __global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
     auto store_row_edge = [&](const f32x16 (&acc)[2], int yy) {       // a branch per access instead of 32 live offset registers
       const unsigned rowpix = (unsigned)((n * a.H + yy) * a.W + x0);
       if (yy >= y1) return;
+      if (SPADE) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          if ((inw >> q) & 1u) {
+            const unsigned pq = rowpix + (unsigned)((q & 3) + 8 * (q >> 2));
+            const float g = acc[0][q] + bv[0], bt = acc[1][q] + bv[1];
+            const float xv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res_rs, vo_res[0], (int)(pq * ldrb), 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), g_rs, vo_g, (int)(pq * ldgb), AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaf(xv, 1.f + g, bt)), out_rs, vo_out[0], (int)(pq * ldob), AUX);
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -602,6 +637,7 @@ int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
   a.C = d->C1; a.ld = d->ld1; a.N = d->N; a.H = d->H; a.W = d->W; a.Kp = d->Kp; a.kmode = d->kmode;
   a.ldr = d->ldr; a.Cout = d->Cout; a.ldo = d->ldo; a.ntaps = d->ntaps;
   a.act = d->act; a.slope = d->slope;
+  a.gsave = nullptr; a.ldg = 0;
   window_taps(d, a.tapidx);
   a.nt_store = (long long)d->N * d->H * d->W * d->ldo * 4 >= (256ll << 20);
   bool ks1 = true;
@@ -633,11 +669,11 @@ int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
     static const int nt32 = [] { const char* e = getenv("SSG_THIN32_NT"); return e ? atoi(e) : 1; }();
     const bool nt = nt32 && a.nt_store;
     if (d->res) {
-      if (nt) hipLaunchKernelGGL((thin32_cin_kernel<true, 1, true>), grid2, block, 0, st, a);
-      else hipLaunchKernelGGL((thin32_cin_kernel<true, 1, false>), grid2, block, 0, st, a);
+      if (nt) hipLaunchKernelGGL((thin32_cin_kernel<1, 1, true>), grid2, block, 0, st, a);
+      else hipLaunchKernelGGL((thin32_cin_kernel<1, 1, false>), grid2, block, 0, st, a);
     } else {
-      if (nt) hipLaunchKernelGGL((thin32_cin_kernel<false, 1, true>), grid2, block, 0, st, a);
-      else hipLaunchKernelGGL((thin32_cin_kernel<false, 1, false>), grid2, block, 0, st, a);
+      if (nt) hipLaunchKernelGGL((thin32_cin_kernel<0, 1, true>), grid2, block, 0, st, a);
+      else hipLaunchKernelGGL((thin32_cin_kernel<0, 1, false>), grid2, block, 0, st, a);
     }
     SSG_LAUNCH_CHECK();
     return SSG_OK;
@@ -660,6 +696,45 @@ int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
       else hipLaunchKernelGGL((thin4_cout_kernel<3, 2>), grid, block, 0, st, a);
     }
   }
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+// ------------------------------------------------------------------ SPADE: gamma|beta conv + modulation in one kernel
+static bool spade_fused_ok(const ssg_conv_desc* d) {
+  static const int on = [] { const char* e = getenv("SSG_SPADE_FUSED"); return e ? atoi(e) : 1; }();     // 0: conv + modulate pass (A/B)
+  if (!on || !d || d->res || d->act != SSG_ACT_NONE || d->bnpart || (d->Cout & 7)) return false;
+  const int kind = ssg_thin4_conv_kind(d);
+  if (kind != 3 || d->ntaps != 9) return false;
+  ssg_conv_desc h = *d;                 // routes_thin32 looks at the conv as if it wrote Cout channels; the size rule is about pixels
+  return routes_thin32(&h, kind) && (long long)d->N * d->H * d->W * (d->Cout / 2) < (1ll << 30);
+}
+
+extern "C" int ssg_spade_conv_modulate_ok(const ssg_conv_desc* d) { return spade_fused_ok(d) ? 1 : 0; }
+
+extern "C" int ssg_spade_conv_modulate_f32(const ssg_conv_desc* d, const float* x, int ldx, float* gamma, int ldg, void* stream) {
+  SSG_REQUIRE(d && x && gamma && d->in1 && d->w && d->out, SSG_EINVAL, "spade_conv_modulate: null pointer");
+  SSG_REQUIRE(spade_fused_ok(d), SSG_EINVAL, "spade_conv_modulate: shape not handled by the fused kernel (ssg_spade_conv_modulate_ok == 0)");
+  const int C = d->Cout / 2;
+  SSG_REQUIRE(ldx >= C && ldg >= C && d->ldo >= C, SSG_EINVAL, "spade_conv_modulate: pixel strides < C");
+  T4Args a;
+  a.in = d->in1; a.w = d->w; a.bias = d->bias; a.res = x; a.out = d->out;
+  a.C = d->C1; a.ld = d->ld1; a.N = d->N; a.H = d->H; a.W = d->W; a.Kp = d->Kp; a.kmode = d->kmode;
+  a.ldr = ldx; a.Cout = d->Cout; a.ldo = d->ldo; a.ntaps = d->ntaps;
+  a.act = SSG_ACT_NONE; a.slope = 0.f;
+  a.gsave = gamma; a.ldg = ldg;
+  window_taps(d, a.tapidx);
+  a.nt_store = (long long)d->N * d->H * d->W * C * 4 >= (256ll << 20);
+  a.groups = (C + 31) / 32;
+  a.strips = (d->W + 31) / 32;
+  a.ybands = (d->H + RH_K36 - 1) / RH_K36;
+  a.total_units = d->N * a.ybands * a.strips;
+  int wpg = 8192 / a.groups;
+  if (wpg > a.total_units) wpg = a.total_units;
+  a.waves_per_group = wpg;
+  const dim3 grid((unsigned)((wpg * a.groups + 3) / 4)), block(256);
+  if (a.nt_store) hipLaunchKernelGGL((thin32_cin_kernel<2, 1, true>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((thin32_cin_kernel<2, 1, false>), grid, block, 0, (hipStream_t)stream, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -72,6 +72,42 @@ def test_spade(pkg, dev, gold, tag):
     _check(m, gold, tag, dev, fwd=lambda x: m(x, x))
 
 
+def test_spade_fused_gamma_beta_modulate(pkg, dev):
+    """SPADE at a size the fused kernel takes (4-channel hidden activation, >= 65536 pixels: gamma|beta conv + modulation in
+    ssg_spade_conv_modulate_f32, gamma-only tensor kept for the backward) against the block's arithmetic in torch fp64 on the
+    CPU (normalization.py:110-120), forward and every gradient."""
+    import torch.nn.functional as F
+    torch.manual_seed(21)
+    c, h, w = 64, 256, 257                                   # ragged width: edge strips of the 32-pixel kernel
+    m = pkg.normalization.SPADE('spadebatch3x3', c, 3, c / 16).to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, c, h, w, generator=g); dy = torch.randn(1, c, h, w, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    pkg.ops.PROFILE = []
+    try:
+        yd = m(xd, xd)
+        labels = [r[0] for r in pkg.ops.PROFILE]
+    finally:
+        pkg.ops.PROFILE = None
+    assert 'thin32_cin_kernel<spade>' in labels, labels
+    yd.backward(dy.to(dev))
+    P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.named_parameters()}
+    xr = x.double().requires_grad_(True)
+    seg = F.conv2d(xr, P['x2map.weight'], P['x2map.bias'], 1, 1)
+    a = F.relu(F.conv2d(seg, P['mlp_shared.0.weight'], P['mlp_shared.0.bias'], 1, 1))
+    gam = F.conv2d(a, P['mlp_gamma.weight'], P['mlp_gamma.bias'], 1, 1); bet = F.conv2d(a, P['mlp_beta.weight'], P['mlp_beta.bias'], 1, 1)
+    yr = xr * (1 + gam) + bet
+    yr.backward(dy.double())
+
+    def close(got, ref, nm, rtol=2e-5):
+        e = (got.detach().cpu().double() - ref).abs().max().item()
+        assert e <= rtol * ref.abs().max().item() + 1e-6, '%s: max err %.3e (ref max %.3e)' % (nm, e, ref.abs().max().item())
+    close(yd, yr.detach(), 'out')
+    close(xd.grad, xr.grad, 'dx', 5e-5)
+    for k, v in m.named_parameters():
+        close(v.grad, P[k].grad, k, 2e-4)
+
+
 @pytest.mark.parametrize('tag', ['cb_a', 'cb_b', 'cb_c'])
 def test_convolutional_block(pkg, dev, gold, tag):
     cin, cout, s, bn, hw = [int(v) for v in gold[tag + '_cfg']]
