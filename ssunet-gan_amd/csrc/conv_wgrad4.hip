@@ -121,6 +121,97 @@ __global__ __launch_bounds__(256) void wgrad4_kernel(const W4Args a) {
   }
 }
 
+// ------------------------------------------------------------------ thin-Cin (in has 4 channels, 3x3) on the 32x32x2 MFMA
+// dw[co][tap][c] = sum_p dout[p][co] * in[p + tap][c] as a GEMM with M = 64 output channels (two fragments), N = (tap, c) = 36
+// columns (two fragments, the second holds tap 8 only) and K = pixels, two per MFMA: A = dout[p + h][co0 + m] (one dword per
+// lane: lanes 0-31 / 32-63 read one whole 128-byte line each), B = in[p + h + tap(n)][c(n)].  8 instructions per 2 pixels
+// instead of the 4x4x1 kernel's 110 per 8 (which runs at 2.2 TB/s of dout): the same slab / ordered-reduce protocol.
+__global__ __launch_bounds__(256) void wgrad32_cin_kernel(const W4Args a) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const int zb = blockIdx.x / a.groups, cg = blockIdx.x - zb * a.groups;
+  const int z = zb * 4 + wave;
+  const unsigned npix = (unsigned)(a.N * a.H * a.W);
+  const auto do_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wide), 0, (int)(npix * (unsigned)a.ldw * 4u), 0x00020000);
+  const auto in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.thin), 0, (int)(npix * (unsigned)a.ldt * 4u), 0x00020000);
+  constexpr unsigned OOB = 0xffffffffu;
+  const unsigned ldwb = (unsigned)a.ldw * 4u, ldtb = (unsigned)a.ldt * 4u;
+  // A: this lane's two output channels; B: this lane's (tap, channel) columns n = l31 and 32 + l31 (only taps 0..8 exist)
+  unsigned aoff[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) { const int co = cg * 64 + f * 32 + l31; aoff[f] = co < a.Cout ? (unsigned)co * 4u : OOB; }
+  const int t0 = l31 >> 2, c = l31 & 3;                  // column n = l31: tap 0..7; column 32 + l31: tap 8 for l31 < 4
+  const int dy0 = t0 / 3 - 1, dx0 = t0 % 3 - 1;
+  const bool has1 = l31 < 4;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[f][g][q] = 0.f;
+
+  const int u0 = z * (int)a.units_per_z;
+  const int total_units = a.N * a.H * a.segs_per_row;
+  int u1 = u0 + (int)a.units_per_z; if (u1 > total_units) u1 = total_units;
+  constexpr int UP = 8;                                  // pixel pairs per inner step (16: 172 registers, 2 waves per SIMD, 3 % slower)
+  for (int u = u0; u < u1; ++u) {
+    const int r = u / a.segs_per_row; const int seg = u - r * a.segs_per_row;
+    const int y = r % a.H, n = r / a.H;
+    const int x0 = seg * SEG;
+    const int x1 = x0 + SEG < a.W ? x0 + SEG : a.W;
+    const unsigned rowpix = (unsigned)((n * a.H + y) * a.W);
+    const bool r0ok = (unsigned)(y + dy0) < (unsigned)a.H, r1ok = has1 && y + 1 < a.H;
+    const unsigned b0row = (rowpix + (unsigned)(dy0 * a.W)) * ldtb + (unsigned)c * 4u;
+    const unsigned b1row = (rowpix + (unsigned)a.W) * ldtb + (unsigned)c * 4u;
+    for (int xb = x0; xb < x1; xb += 2 * UP) {
+      float av[2][UP], bv[2][UP];
+#pragma unroll
+      for (int k = 0; k < UP; ++k) {
+        const int x = xb + 2 * k + h;
+        const bool pok = x < x1;
+        const unsigned po = (rowpix + (unsigned)x) * ldwb;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+          av[f][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(do_rs, (pok && aoff[f] != OOB) ? po + aoff[f] : OOB, 0, 0));
+        const int ix0 = x + dx0, ix1 = x + 1;
+        bv[0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            in_rs, (pok && r0ok && (unsigned)ix0 < (unsigned)a.W) ? b0row + (unsigned)ix0 * ldtb : OOB, 0, 0));
+        bv[1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            in_rs, (pok && r1ok && ix1 < a.W) ? b1row + (unsigned)ix1 * ldtb : OOB, 0, 0));
+      }
+#pragma unroll
+      for (int k = 0; k < UP; ++k)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f][k], bv[g][k], acc[f][g], 0, 0, 0);
+    }
+  }
+  // fold the 4 waves through LDS in wave order; D[m = co][n]: lane holds column n = l31 (+32 g), rows (q&3) + 8*(q>>2) + 4*h (+32 f)
+  __shared__ float red[4][36][64];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int nn = g * 32 + l31;
+      if (nn < 36) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[wave][nn][f * 32 + (q & 3) + 8 * (q >> 2) + 4 * h] = acc[f][g][q];
+      }
+    }
+  __syncthreads();
+  float* slab = a.ws + (size_t)zb * 9 * a.Cin * a.Cout;          // [slab][row = t*Cin + c][Cout], Cin == 4: row = n
+  for (int e = threadIdx.x; e < 36 * 64; e += 256) {
+    const int nn = e >> 6, m = e & 63;
+    const float sum = ((red[0][nn][m] + red[1][nn][m]) + red[2][nn][m]) + red[3][nn][m];
+    const int co = cg * 64 + m;
+    if (co < a.Cout) slab[(size_t)nn * a.Cout + co] = sum;
+  }
+}
+
 // ------------------------------------------------------------------ tiny: in has 4 channels AND dout has <= 8 (SPADE's 3 -> nhidden
 // conv, normalization.py:92).  VALU: thread (pixel slot k = tid / 8, output channel co = tid % 8) walks the workgroup's pixel
 // range with stride 32, 36 accumulators dw[co][tap][c]; the 9 window loads are shared by the 8 channel threads of a pixel
@@ -171,7 +262,8 @@ __global__ __launch_bounds__(256) void wgrad_tiny4_kernel(const W4Args a) {
 
 }  // namespace
 
-// kind 5: dout thin (Cout <= 4), kind 6: in thin (Cin_pad == 4), kind 7: both (Cin_pad == 4, Cout <= 8; VALU)
+// kind 5: dout thin (Cout <= 4), kind 6: in thin (Cin_pad == 4), kind 7: both (Cin_pad == 4, Cout <= 8; VALU),
+// kind 8: in thin, 3x3, Cout >= 32 on >= 65536 pixels (32x32x2 MFMA)
 int ssg_wgrad4_kind(const ssg_wgrad_desc* d) {
   if (d->C2 != 0 || d->in_sy != 1 || d->in_sx != 1 || d->GH != d->H || d->GW != d->W) return 0;
   if (d->ntaps == 9) {
@@ -184,6 +276,8 @@ int ssg_wgrad4_kind(const ssg_wgrad_desc* d) {
   if (d->Cout <= 4 && d->C1 >= 16 && d->C1 % 4 == 0) return 5;
   static const int tiny = [] { const char* e = getenv("SSG_TINY4"); return e ? atoi(e) : 1; }();
   if (tiny && d->C1 == 4 && d->Cout <= 8 && d->ntaps == 9) return 7;
+  static const int w32 = [] { const char* e = getenv("SSG_WGRAD32"); return e ? atoi(e) : 1; }();
+  if (w32 && d->C1 == 4 && d->ntaps == 9 && d->Cout >= 32 && (long long)d->N * d->H * d->W >= 65536) return 8;
   if (d->C1 == 4) return 6;
   return 0;
 }
@@ -219,6 +313,12 @@ int ssg_wgrad4_launch(const ssg_wgrad_desc* d, int kind, hipStream_t st) {
   if (kind == 7) {
     a.wide = d->dout; a.Cw = d->Cout; a.ldw = d->ldd; a.thin = d->in1; a.ldt = d->ld1;
     hipLaunchKernelGGL(wgrad_tiny4_kernel, grid, block, 0, st, a);
+    SSG_LAUNCH_CHECK();
+    return SSG_OK;
+  }
+  if (kind == 8) {
+    a.wide = d->dout; a.Cw = d->Cout; a.ldw = d->ldd; a.thin = d->in1; a.ldt = d->ld1;
+    hipLaunchKernelGGL(wgrad32_cin_kernel, grid, block, 0, st, a);
     SSG_LAUNCH_CHECK();
     return SSG_OK;
   }

@@ -188,7 +188,7 @@ _CONV_LABELS = {0: 'conv_igemm_kernel<128,128>', 1: 'conv_igemm_kernel<256,64>',
 _WGRAD_LABELS = {0: 'wgrad_kernel<128,128>', 1: 'wgrad_kernel<128,64>', 2: 'wgrad_kernel<128,32>',
                  20: 'wgrad_dma_kernel<128,128>', 21: 'wgrad_dma_kernel<128,64>',
                  30: 'wgrad_halo_kernel<32,128>', 31: 'wgrad_halo_kernel<64,64>',
-                 15: 'wgrad4_kernel<thin_cout>', 16: 'wgrad4_kernel<thin_cin>', 17: 'wgrad_tiny4_kernel'}
+                 15: 'wgrad4_kernel<thin_cout>', 16: 'wgrad4_kernel<thin_cin>', 17: 'wgrad_tiny4_kernel', 18: 'wgrad32_cin_kernel'}
 
 
 class _Timed(object):

@@ -66,8 +66,8 @@ def test_conv2d_fwd_bwd(pkg, dev, case):
 KERNEL_CASES = [
     # n, cin, cout, h, w, k, pad, kernels that must have run (forward, input gradient, weight gradient)
     (2, 3, 64, 37, 45, 3, 1, ('thin4_cin_kernel', 'thin4_cout_kernel', 'wgrad4_kernel<thin_cin>')),
-    (2, 3, 64, 150, 237, 3, 1, ('thin32_cin_kernel', 'thin4_cout_kernel', 'wgrad4_kernel<thin_cin>')),   # >= 65536 pixels: 32-pixel strips
-    (1, 4, 96, 260, 270, 3, 1, ('thin32_cin_kernel',)),                    # two 64-channel groups, the second half empty; full + edge strips
+    (2, 3, 64, 150, 237, 3, 1, ('thin32_cin_kernel', 'thin4_cout_kernel', 'wgrad32_cin_kernel')),   # >= 65536 pixels: 32-pixel strips
+    (1, 4, 96, 260, 270, 3, 1, ('thin32_cin_kernel', 'wgrad32_cin_kernel')),                    # two 64-channel groups, the second half empty; full + edge strips
     (2, 3, 4, 37, 45, 3, 1, ('tiny4_kernel', 'wgrad_tiny4_kernel')),       # 4 -> <= 8 channels: VALU kernels
     (1, 4, 7, 19, 70, 3, 1, ('tiny4_kernel', 'wgrad_tiny4_kernel')),
     (2, 3, 64, 16, 20, 1, 0, ('thin4_cin_kernel',)),                       # 1x1 with a 4-channel input stays on the 4x4x1 kernel
