@@ -97,18 +97,19 @@ def _spade_cat(wg, bg, wb, bb):
 
 
 def _spade_fused_fwd(x, a, wgb, bgb, pad, out):
-    """gamma|beta conv + modulation in one kernel (ssg_spade_conv_modulate_f32) where the shape allows it (4-channel `a`, 3x3,
-    >= 65536 pixels: the 512^2 level at batch 16).  Writes `out`, returns gamma (needed by the backward) or None."""
+    """gamma|beta conv + modulation in one kernel (ssg_spade_conv_modulate_f32) where the shape allows it (4- or 8-channel `a`,
+    3x3, >= 65536 pixels: the 512^2 and 256^2 levels at batch 16).  Writes `out`, returns gamma (needed by the backward) or None."""
     o, i, kh, kw = wgb.shape
     n, c, h, w = x.shape
-    if kh != 3 or kw != 3 or pad != 1 or ops.pad4(a.shape[1]) != 4 or o != 2 * c or c % 4:
+    cin = ops.pad4(a.shape[1])
+    if kh != 3 or kw != 3 or pad != 1 or cin not in (4, 8) or o != 2 * c or c % 4:
         return None
     from ._lib import ConvDesc
     import ctypes as C
     taps = ops._taps_fwd(kh, kw, pad)
-    wpk, kp, kmode = ops._pack(wgb, 0, taps, 4, 4)
+    wpk, kp, kmode = ops._pack(wgb, 0, taps, cin, cin)
     d = ConvDesc()
-    d.in1 = a.data_ptr(); d.C1 = 4; d.ld1 = _ld(a); d.in2 = None; d.C2 = 0; d.ld2 = 0
+    d.in1 = a.data_ptr(); d.C1 = cin; d.ld1 = _ld(a); d.in2 = None; d.C2 = 0; d.ld2 = 0
     d.N, d.H, d.W = n, h, w
     d.w = wpk.data_ptr(); d.Kp = kp; d.kmode = kmode
     d.bias = bgb.data_ptr(); d.res = None; d.ldr = 0

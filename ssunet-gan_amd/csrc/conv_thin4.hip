@@ -192,9 +192,13 @@ constexpr int RH_K36 = 16;       // output rows per work unit
 // C..2C-1] (a.Cout = 2C), the wave's two N-fragments are gamma and beta of the SAME 32 channels, `res` is the tensor being
 // modulated: out = x * (1 + gamma) + beta, and gamma goes to a.gsave.  The [N,2C,H,W] gamma|beta tensor and the separate
 // modulate pass (3 reads + 1 write of C channels) never exist.
-template <int MODE, int PF, bool NT>
+// CIN = 4: the lane half h owns the channel pair {2h, 2h+1} of a tap (8-byte loads, 18 K-steps); CIN = 8 (SPADE at the 256^2
+// level, nhidden = 8): the quad {4h .. 4h+3} (16-byte loads, 36 K-steps, 72 weight registers).
+template <int MODE, int PF, bool NT, int CIN = 4>
 __global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
   constexpr bool HAS_RES = MODE >= 1, SPADE = MODE == 2;
+  constexpr int CH = CIN / 2;               // channels per lane half and tap
+  typedef float vrow_t __attribute__((ext_vector_type(CH)));
   constexpr int AUX = NT ? 2 : 0;           // non-temporal stores for outputs far larger than the caches
   constexpr int RING = 3 + PF;
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
   const int Cmod = a.Cout >> 1;            // SPADE: channels of x / out / gamma
 
   // B operand: K-step s = 2*p + j (p = window position, j = channel of the lane half's pair) for the lane's output channel
-  float wB[2][18], bv[2], keep[2];       // keep = 0 for the pad lanes [Cout, pad4(Cout)): written as 0
+  float wB[2][9 * CH], bv[2], keep[2];       // keep = 0 for the pad lanes [Cout, pad4(Cout)): written as 0
   unsigned vo_out[2], vo_res[2];         // per-lane part of the byte offset (pixel 4*h of the strip, this lane's channel) or OOB
   unsigned vo_g = OOB;
 #pragma unroll
@@ -222,8 +226,8 @@ __global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
     for (int p = 0; p < 9; ++p) {
       const int t = a.tapidx[p];
       const bool ok = co < a.Cout && t >= 0;
-      const f32x2 w2 = ok ? *(const f32x2*)(a.w + (size_t)co * a.Kp + t * 4 + 2 * h) : f32x2{0.f, 0.f};
-      wB[f][2 * p] = w2[0]; wB[f][2 * p + 1] = w2[1];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) wB[f][CH * p + j] = ok ? a.w[(size_t)co * a.Kp + t * CIN + CH * h + j] : 0.f;
     }
     bv[f] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
     keep[f] = co < a.Cout ? 1.f : 0.f;
@@ -246,21 +250,24 @@ __global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
       const int ix = x + e - 1;
-      coloff[e] = (unsigned)ix < (unsigned)a.W ? (unsigned)ix * ldb + 8u * (unsigned)h : OOB;
+      coloff[e] = (unsigned)ix < (unsigned)a.W ? (unsigned)ix * ldb + (unsigned)(4 * CH) * (unsigned)h : OOB;
     }
     const unsigned imgoff = (unsigned)(n * a.H) * (unsigned)a.W * ldb;
-    auto load_row = [&](f32x2* dst, int iy) {
+    auto load_row = [&](vrow_t* dst, int iy) {
       const bool rok = (unsigned)iy < (unsigned)a.H;
       const unsigned ro = imgoff + (unsigned)iy * (unsigned)a.W * ldb;
 #pragma unroll
-      for (int e = 0; e < 3; ++e) dst[e] = ldbuf2(in_rs, (rok && coloff[e] != OOB) ? ro + coloff[e] : OOB);
+      for (int e = 0; e < 3; ++e) {
+        const unsigned off = (rok && coloff[e] != OOB) ? ro + coloff[e] : OOB;
+        if constexpr (CIN == 4) dst[e] = ldbuf2(in_rs, off); else dst[e] = ldbuf4(in_rs, off);
+      }
     };
     // accumulator register q holds pixel column (q&3) + 8*(q>>2) + 4*h of the strip; bit q of `inw`: that column is inside the image
     unsigned inw = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) inw |= (x0 + (q & 3) + 8 * (q >> 2) + 4 * h < a.W ? 1u : 0u) << q;
     const bool full = x0 + 32 <= a.W;
-    f32x2 v[RING][3];
+    vrow_t v[RING][3];
 #pragma unroll
     for (int q = 0; q < 2 + PF; ++q) load_row(v[q], y0 - 1 + q);
     auto mma_row = [&](f32x16 (&acc)[2], int r) {        // output row whose window rows sit in ring slots r, r+1, r+2
@@ -273,10 +280,10 @@ __global__ __launch_bounds__(256) void thin32_cin_kernel(const T4Args a) {
 #pragma unroll
         for (int e = 0; e < 3; ++e)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < CH; ++j)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
-              acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[(r + q) % RING][e][j], wB[f][2 * (q * 3 + e) + j], acc[f], 0, 0, 0);
+              acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[(r + q) % RING][e][j], wB[f][CH * (q * 3 + e) + j], acc[f], 0, 0, 0);
     };
     auto store_row_full = [&](const f32x16 (&acc)[2], int yy) {       // whole strip inside the image: per-lane offset is
       const unsigned rowpix = (unsigned)((n * a.H + yy) * a.W + x0);  // loop-invariant, the rest rides the scalar offset
@@ -701,14 +708,23 @@ int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ SPADE: gamma|beta conv + modulation in one kernel
-static bool spade_fused_ok(const ssg_conv_desc* d) {
-  static const int on = [] { const char* e = getenv("SSG_SPADE_FUSED"); return e ? atoi(e) : 1; }();     // 0: conv + modulate pass (A/B)
-  if (!on || !d || d->res || d->act != SSG_ACT_NONE || d->bnpart || (d->Cout & 7)) return false;
-  const int kind = ssg_thin4_conv_kind(d);
-  if (kind != 3 || d->ntaps != 9) return false;
-  ssg_conv_desc h = *d;                 // routes_thin32 looks at the conv as if it wrote Cout channels; the size rule is about pixels
-  return routes_thin32(&h, kind) && (long long)d->N * d->H * d->W * (d->Cout / 2) < (1ll << 30);
+// 4 = the 4-channel-input kernel, 8 = the 8-channel one, 0 = not handled
+static int spade_fused_cin(const ssg_conv_desc* d) {
+  static const int on = [] { const char* e = getenv("SSG_SPADE_FUSED"); return e ? atoi(e) : 1; }();     // 0: conv + modulate pass (A/B); 4: only the 4-channel form
+  if (!on || !d || d->res || d->act != SSG_ACT_NONE || d->bnpart || (d->Cout & 7) || d->ntaps != 9 || d->kmode != 1) return 0;
+  if (d->C2 != 0 || d->in_sy != 1 || d->in_sx != 1 || d->out_sy != 1 || d->out_sx != 1 || d->out_oy || d->out_ox) return 0;
+  if (d->GH != d->H || d->GW != d->W || d->OH != d->H || d->OW != d->W) return 0;
+  if (((uintptr_t)d->in1 & 15) || d->ld1 % 4 || ((uintptr_t)d->w & 15) || d->Kp % 4 || d->ldo % 4 || ((uintptr_t)d->out & 15)) return 0;
+  int tapidx[9];
+  if (!window_taps(d, tapidx)) return 0;
+  if (d->W < 32 || (long long)d->N * d->H * d->W < 65536) return 0;
+  if ((long long)d->N * d->H * d->W * (d->Cout / 2) >= (1ll << 30) || (long long)d->N * d->H * d->W * d->ld1 >= (1ll << 30)) return 0;
+  if (d->C1 == 4) return 4;
+  if (d->C1 == 8 && on != 4) return 8;
+  return 0;
 }
+
+static bool spade_fused_ok(const ssg_conv_desc* d) { return spade_fused_cin(d) != 0; }
 
 extern "C" int ssg_spade_conv_modulate_ok(const ssg_conv_desc* d) { return spade_fused_ok(d) ? 1 : 0; }
 
@@ -733,7 +749,10 @@ extern "C" int ssg_spade_conv_modulate_f32(const ssg_conv_desc* d, const float* 
   if (wpg > a.total_units) wpg = a.total_units;
   a.waves_per_group = wpg;
   const dim3 grid((unsigned)((wpg * a.groups + 3) / 4)), block(256);
-  if (a.nt_store) hipLaunchKernelGGL((thin32_cin_kernel<2, 1, true>), grid, block, 0, (hipStream_t)stream, a);
+  if (spade_fused_cin(d) == 8) {
+    if (a.nt_store) hipLaunchKernelGGL((thin32_cin_kernel<2, 1, true, 8>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((thin32_cin_kernel<2, 1, false, 8>), grid, block, 0, (hipStream_t)stream, a);
+  } else if (a.nt_store) hipLaunchKernelGGL((thin32_cin_kernel<2, 1, true>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((thin32_cin_kernel<2, 1, false>), grid, block, 0, (hipStream_t)stream, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;

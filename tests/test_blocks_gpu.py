@@ -72,13 +72,14 @@ def test_spade(pkg, dev, gold, tag):
     _check(m, gold, tag, dev, fwd=lambda x: m(x, x))
 
 
-def test_spade_fused_gamma_beta_modulate(pkg, dev):
+@pytest.mark.parametrize('c,h,w', [(64, 256, 257), (128, 130, 515)])
+def test_spade_fused_gamma_beta_modulate(pkg, dev, c, h, w):
     """SPADE at a size the fused kernel takes (4-channel hidden activation, >= 65536 pixels: gamma|beta conv + modulation in
     ssg_spade_conv_modulate_f32, gamma-only tensor kept for the backward) against the block's arithmetic in torch fp64 on the
     CPU (normalization.py:110-120), forward and every gradient."""
     import torch.nn.functional as F
     torch.manual_seed(21)
-    c, h, w = 64, 256, 257                                   # ragged width: edge strips of the 32-pixel kernel
+    # ragged widths: edge strips of the 32-pixel kernel; c = 64 -> nhidden 4 (8-byte loads), c = 128 -> nhidden 8 (16-byte loads)
     m = pkg.normalization.SPADE('spadebatch3x3', c, 3, c / 16).to(dev).train()
     g = torch.Generator().manual_seed(5)
     x = torch.randn(1, c, h, w, generator=g); dy = torch.randn(1, c, h, w, generator=g)
