@@ -7,10 +7,12 @@ whole block is ONE autograd node: the backward pass is an explicit kernel schedu
 those gradient sums ride the dgrad kernel's residual epilogue, the ReLU masks are folded into
 the batch-norm backward kernels, and `torch.cat` never materialises (two-pointer convs).
 """
+import ctypes as C
+
 import torch
 
 from . import ops
-from ._lib import ACT_NONE, ACT_RELU, call, ptr, stream_ptr
+from ._lib import ACT_NONE, ACT_RELU, ConvDesc, call, ptr, stream_ptr
 from .ops import (_act_bwd, _bn_bwd_impl, _bn_fwd_impl, _channel_sum, _conv_dgrad_impl, _conv_fwd_impl, _conv_wgrad_impl,
                   _ld, new_nhwc, to_nhwc)
 
@@ -104,8 +106,6 @@ def _spade_fused_fwd(x, a, wgb, bgb, pad, out):
     cin = ops.pad4(a.shape[1])
     if kh != 3 or kw != 3 or pad != 1 or cin not in (4, 8) or o != 2 * c or c % 4:
         return None
-    from ._lib import ConvDesc
-    import ctypes as C
     taps = ops._taps_fwd(kh, kw, pad)
     wpk, kp, kmode = ops._pack(wgb, 0, taps, cin, cin)
     d = ConvDesc()

@@ -74,3 +74,13 @@ def test_bad_arguments_return_status_not_crash(pkg):
         assert False
     except RuntimeError as e:
         assert 'ssg_conv2d_igemm_f32 failed' in str(e)
+
+
+def test_fused_spade_entry_rejects_unsupported_descriptors(pkg):
+    """ssg_spade_conv_modulate_ok is a pure host-side predicate; the launcher refuses what the predicate refuses (no GPU needed)."""
+    lib = pkg._lib
+    d = lib.ConvDesc()
+    assert lib.call('ssg_spade_conv_modulate_ok', ctypes.byref(d)) == 0
+    assert lib.call('ssg_conv2d_workspace_bytes', ctypes.byref(d)) == 0
+    rc = lib.load().ssg_spade_conv_modulate_f32(ctypes.byref(d), None, 0, None, 0, None)
+    assert rc != 0 and b'spade_conv_modulate' in lib.load().ssg_last_error()
