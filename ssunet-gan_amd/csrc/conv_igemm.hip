@@ -354,13 +354,15 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
 //   0..2 = conv_igemm<128,128> / <256,64> / <256,32>, 20/21/22 = conv_igemm_dma<128,128> / <256,64> / <128,64>,
 //   30/31/32 = conv_igemm_halo<128,128> / <256,64> / <128,64>, 33/34 = conv_igemm_halo16<128,128> / <128,64> (8x16-pixel tiles),
 //   12 = thin4 (4x4x1 MFMA) 4-channel input, 13 = thin4 Cout <= 4, 14 = tiny4 (4 -> <= 8 channels, VALU), 15 = thin32
-//   (4-channel input, 3x3, Cout >= 32 on the 32x32x2 MFMA), 10 = thin small-Cout (VALU).
+//   (4-channel input, 3x3, Cout >= 32 on the 32x32x2 MFMA), 16 = conv1x1_k64 (streaming 1x1, 64 input channels),
+//   10 = thin small-Cout (VALU).
 extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
   if (!d) return SSG_EINVAL;
   const int k4 = ssg_thin4_conv_kind(d);
   if (k4) return ssg_thin4_conv_id(d, k4);
   const int k = ssg_thin_conv_kind(d);
   if (k) return 9 + k;
+  if (ssg_conv1x1_k64_ok(d)) return 16;
   if (uses_dma(d)) return uses_halo(to_args(d)) ? 30 + ssg_conv_halo_variant(to_args(d), pick_variant(d)) : 20 + ssg_conv_dma_variant(to_args(d), pick_variant(d));
   return pick_variant(d);
 }
@@ -373,5 +375,6 @@ extern "C" int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream) {
   SSG_REQUIRE(!d->bnpart || !(k4 || k), SSG_EINVAL, "conv: bnpart given but this shape has no statistics epilogue (ssg_conv2d_bnpart_rows == 0)");
   if (k4) return ssg_thin4_conv_launch(d, k4, (hipStream_t)stream);
   if (k) return ssg_thin_conv_launch(d, k, (hipStream_t)stream);
+  if (ssg_conv1x1_k64_ok(d)) return ssg_conv1x1_k64_launch(d, (hipStream_t)stream);
   return ssg_conv2d_igemm_f32(d, stream);
 }

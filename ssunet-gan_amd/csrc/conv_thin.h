@@ -11,3 +11,6 @@ int ssg_wgrad4_launch(const ssg_wgrad_desc* d, int kind, hipStream_t st);
 int ssg_thin4_conv_kind(const ssg_conv_desc* d);
 int ssg_thin4_conv_launch(const ssg_conv_desc* d, int kind, hipStream_t st);
 int ssg_thin4_conv_id(const ssg_conv_desc* d, int kind);      // profiling label id (12..15)
+// conv_1x1.hip: 1x1 convs with 64 input channels as a streaming GEMM (weights in registers)
+int ssg_conv1x1_k64_ok(const ssg_conv_desc* d);
+int ssg_conv1x1_k64_launch(const ssg_conv_desc* d, hipStream_t st);

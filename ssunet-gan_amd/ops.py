@@ -184,7 +184,7 @@ _CONV_LABELS = {0: 'conv_igemm_kernel<128,128>', 1: 'conv_igemm_kernel<256,64>',
                 30: 'conv_igemm_halo_kernel<128,128>', 31: 'conv_igemm_halo_kernel<256,64>', 32: 'conv_igemm_halo_kernel<128,64>',
                 33: 'conv_igemm_halo16_kernel<128,128>', 34: 'conv_igemm_halo16_kernel<128,64>',
                 10: 'thin_small_cout_kernel',
-                12: 'thin4_cin_kernel', 13: 'thin4_cout_kernel', 14: 'tiny4_kernel', 15: 'thin32_cin_kernel'}
+                12: 'thin4_cin_kernel', 13: 'thin4_cout_kernel', 14: 'tiny4_kernel', 15: 'thin32_cin_kernel', 16: 'conv1x1_k64_kernel'}
 _WGRAD_LABELS = {0: 'wgrad_kernel<128,128>', 1: 'wgrad_kernel<128,64>', 2: 'wgrad_kernel<128,32>',
                  20: 'wgrad_dma_kernel<128,128>', 21: 'wgrad_dma_kernel<128,64>',
                  30: 'wgrad_halo_kernel<32,128>', 31: 'wgrad_halo_kernel<64,64>',

@@ -87,6 +87,8 @@ KERNEL_CASES = [
     (1, 256, 24, 10, 33, 3, 1, ('conv_igemm_halo_kernel<128,64>+splitk',)),
     (1, 96, 64, 9, 33, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_dma_kernel<128,64>')),
     (2, 48, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,128>')),            # short K: the small DMA tile
+    (1, 64, 96, 256, 257, 1, 0, ('conv1x1_k64_kernel',)),                  # streaming 1x1, K = 64; partial last block, half-empty group
+    (1, 128, 64, 260, 256, 1, 0, ('conv1x1_k64_kernel',)),                 # ... as the input gradient of a 128 -> 64 conv
     (1, 320, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,128>', 'conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,128>')),
     (1, 320, 48, 14, 14, 1, 0, ('conv_igemm_dma_kernel<256,64>', 'conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,64>')),
 ]
@@ -146,6 +148,25 @@ def test_thin32_forward_with_activation(pkg, dev, act):
     _close(yd, yr, 1e-5, 2e-6 * math.sqrt(27), 'thin32 fwd + act')
     yd2 = pkg.ops.conv2d(x.to(dev), wt.to(dev), None, 1, 1, act=pkg._lib.ACT_RELU)          # no residual: the other instantiation
     _close(yd2, F.relu(F.conv2d(x, wt, None, 1, 1)), 1e-5, 2e-6 * math.sqrt(27), 'thin32 fwd relu')
+
+
+@pytest.mark.parametrize('act', ['relu', 'lrelu'])
+def test_conv1x1_k64_forward_with_activation(pkg, dev, act):
+    """The streaming 1x1 kernel with bias + residual + activation (forward only, see test_thin32_forward_with_activation)."""
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(2, 64, 181, 182, generator=g); wt = torch.randn(72, 64, 1, 1, generator=g) / 8
+    b = torch.randn(72, generator=g); rs = torch.randn(2, 72, 181, 182, generator=g)
+    yr = F.conv2d(x, wt, b) + rs
+    yr = F.relu(yr) if act == 'relu' else F.leaky_relu(yr, 0.2)
+    pkg.ops.PROFILE = []
+    try:
+        yd = pkg.ops.conv2d(x.to(dev), wt.to(dev), b.to(dev), 1, 0, act=pkg._lib.ACT_RELU if act == 'relu' else pkg._lib.ACT_LRELU,
+                            slope=0.2, res=rs.to(dev))
+        labels = [rec[0] for rec in pkg.ops.PROFILE]
+    finally:
+        pkg.ops.PROFILE = None
+    assert labels == ['conv1x1_k64_kernel'], labels
+    _close(yd, yr, 1e-5, 2e-5, 'conv1x1_k64 fwd + act')
 
 
 def _random_conv_cases(count=28, seed=2024):
