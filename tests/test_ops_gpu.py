@@ -88,6 +88,8 @@ KERNEL_CASES = [
     (1, 96, 64, 9, 33, 3, 1, ('conv_igemm_halo_kernel<128,64>', 'wgrad_dma_kernel<128,64>')),
     (2, 48, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,128>')),            # short K: the small DMA tile
     (1, 64, 96, 256, 257, 1, 0, ('conv1x1_k64_kernel',)),                  # streaming 1x1, K = 64; partial last block, half-empty group
+    (1, 64, 66, 130, 515, 1, 0, ('conv1x1_k64_kernel',)),                  # ... Cout % 4 != 0: pad lanes written as 0
+    (2, 3, 5, 16, 20, 1, 0, ('tiny4_kernel',)),                            # 1x1 between <= 4 and <= 8 channels
     (1, 128, 64, 260, 256, 1, 0, ('conv1x1_k64_kernel',)),                 # ... as the input gradient of a 128 -> 64 conv
     (1, 320, 80, 14, 14, 1, 0, ('conv_igemm_dma_kernel<128,128>', 'conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,128>')),
     (1, 320, 48, 14, 14, 1, 0, ('conv_igemm_dma_kernel<256,64>', 'conv_igemm_dma_kernel<128,64>', 'wgrad_dma_kernel<128,64>')),
