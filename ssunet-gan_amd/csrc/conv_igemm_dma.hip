@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvArgs a) {
     if (rem >= AHEAD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * (A_PC + B_PC)) : "memory");
     else if (AHEAD >= 3 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PC + B_PC) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_lds_reads();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (s + AHEAD < nsteps) issue(s + AHEAD);

@@ -181,6 +181,7 @@ __device__ __forceinline__ void halo_body(const ConvArgs& a) {
 #if SSG_HALO_EXP == 1 || SSG_HALO_EXP == 3
       if (t == 0) __builtin_amdgcn_s_barrier();
 #else
+      wait_lds_reads();                                  // lds_dma.h: the barrier hands stage (s + 2) % 3 to another wave's DMA
       __builtin_amdgcn_s_barrier();
 #endif
       asm volatile("" ::: "memory");

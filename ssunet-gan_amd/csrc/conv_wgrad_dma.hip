@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
   for (int s = 0; s < nsteps; ++s) {
     if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PC + B_PC) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_lds_reads();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (s + 2 < nsteps) issue(s + 2);

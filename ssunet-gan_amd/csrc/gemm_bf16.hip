@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
   if (1 < nsteps) issue(1);
   for (int s = 0; s < nsteps; ++s) {
     if (s + 1 < nsteps) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    wait_lds_reads();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (s + 2 < nsteps) issue(s + 2);
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_bf16_kernel(const WgArgsH a) {
   if (1 < nsteps) issue(1);
   for (int s = 0; s < nsteps; ++s) {
     if (s + 1 < nsteps) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    wait_lds_reads();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (s + 2 < nsteps) issue(s + 2);

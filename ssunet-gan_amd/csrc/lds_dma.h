@@ -16,3 +16,10 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+
+// Every LDS read this wave has issued has returned.  REQUIRED before the workgroup barrier of a DMA ring step: the barrier is
+// what lets another wave's LDS-DMA overwrite the stage those reads target (stage (s+2) % 3 == (s-1) % 3), and s_barrier does
+// not wait for lgkmcnt -- a wave can arrive with its last fragment reads of step s-1 still in the LDS queue.  Without this the
+// round-2 kernels produced a wrong 16-channel x 64-pixel patch in roughly one launch in ten when launched on an idle chip
+// (tools/micro_halo_dbg.py), never in back-to-back launches.
+__device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
