@@ -61,6 +61,32 @@ def pmc_traffic_table():
     return os.path.relpath(files[-1], ROOT), table
 
 
+def csrc_sha1():
+    """sha1 over the kernel sources (csrc/*.hip, *.h, sorted): what a PMC summary was taken on vs what runs now."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, 'ssunet-gan_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h'))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, 'rb').read())
+    return h.hexdigest()[:12]
+
+
+def pmc_traffic_meta(src):
+    """Sidecar written by tools/pmc_traffic.py next to the summary: {'csrc_sha1': ..., 'git_commit': ...} (None for old files)."""
+    if not src:
+        return {}
+    f = os.path.join(ROOT, src[:-4] + '.meta.json')
+    try:
+        return json.load(open(f))
+    except Exception:
+        return {}
+
+
+# SURVEY.md 8(d): the 12 forward 3x3 convs of the six encoder BasicBlocks, 54.7 GMAC per 512^2 image
+ENCODER_3X3_GMAC_PER_IMG_512 = 54.65
+
+
 def pmc_traffic_for(label, table):
     """`label` is ops._CONV_LABELS / _WGRAD_LABELS style ('conv_igemm_halo_kernel<128,128>'): match the symbol whose template
     argument list starts with the label's."""
@@ -146,6 +172,15 @@ def _free_port():
 def launch_ranks(n, argv):
     """Parent of an N-rank run: start `python -m torch.distributed.run` as a CHILD (this process has not touched HIP and
     never will), let the ranks inherit stdout (rank 0 prints the JSON line) and return the child's exit status."""
+    # Under rocprofv3 the profiler's preloaded library has ALREADY initialised the GPU in this process, so starting the launcher
+    # from here is the fork/exec hop of a GPU-initialised process that this pool forbids (it can take the machine down).
+    # Multi-rank profiling wraps each rank's own python process (rocprofv3 ... -- python3 bench.py under torchrun), never this parent.
+    preload = ' '.join(os.environ.get(k, '') for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB'))
+    if 'rocprof' in preload.lower() or any(k.startswith('ROCPROFILER_') or k.startswith('ROCPROF_') for k in os.environ):
+        print('[bench] refusing to self-launch %d ranks under a profiler preload (%s): start the ranks with torch.distributed.run '
+              'and wrap each rank, e.g. torchrun ... --no-python rocprofv3 ... -- python3 bench.py --gpus %d' % (n, preload.strip() or 'ROCPROF*', n),
+              file=sys.stderr)
+        return 2
     env = os.environ.copy()
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # read when HSA initialises in the ranks (dmabuf IPC for RCCL)
     env.setdefault('OMP_NUM_THREADS', '4')
@@ -189,7 +224,7 @@ def launch_check(args):
     if rank == 0:
         print(json.dumps({'metric': 'train images/sec (512^2 tiles)', 'value': None, 'unit': 'images/sec', 'n_gpus': world,
                           'launch_check': True, 'backend': backend, 'rank_sum': float(t.item())}))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
     return 0
 
@@ -240,7 +275,7 @@ def main():
     G = S.models_seg_gan.Generator(dict(arch='UNet_R_SS_v2', num_classes=3, input_channels=3, deep_supervision=False))
     D = S.models_seg_gan.Discriminator(3, kernel_size=3, n_channels=64, n_blocks=8, fc_size=1024)
     G.to(dev).train(); D.to(dev).train()
-    if world > 1:
+    if S.dp.is_dist():                                             # world > 1, or the 1-rank RCCL rehearsal (SSG_DIST_FORCE=1)
         S.dp.broadcast_parameters(G); S.dp.broadcast_parameters(D)
         S.dp.convert_sync_batchnorm(G); S.dp.convert_sync_batchnorm(D)
     og = torch.optim.Adam(params=filter(lambda p: p.requires_grad, G.parameters()), lr=2e-5)
@@ -268,7 +303,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    S.ops.PROFILE = []
+    S.ops.PROFILE = []; S.ops.PROFILE_HBM = []; S.ops.PROFILE_COMM = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -277,9 +312,13 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, S.ops.PROFILE = S.ops.PROFILE, None
+    prof_hbm, S.ops.PROFILE_HBM = S.ops.PROFILE_HBM, None
+    prof_comm, S.ops.PROFILE_COMM = S.ops.PROFILE_COMM, None
     note('timed %d steps: %.1f ms/step' % (args.steps, dt / args.steps * 1e3))
     devices = [torch.cuda.current_device()]
     buckets = None
+    if world == 1 and sync_g is not None:                  # SSG_DIST_FORCE=1: one rank, every collective through the backend
+        buckets = bucket_allreduce_ms((('G', sync_g), ('D', sync_d)), dev)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -294,9 +333,17 @@ def main():
         value = imgs / dt
         # dominant MFMA kernel: aggregate HIP-event durations per kernel symbol
         agg = {}
-        for label, flops, e0, e1 in prof:
+        enc = [0.0, 0.0, 0]                               # FLOPs, seconds, launches of the forward 3x3 convs of the encoder blocks
+        for label, flops, e0, e1, tag in prof:
             a = agg.setdefault(label, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+            sec = e0.elapsed_time(e1) * 1e-3
+            a[0] += flops; a[1] += sec; a[2] += 1
+            if tag == 'encoder_3x3':
+                enc[0] += flops; enc[1] += sec; enc[2] += 1
+        hbm = {}
+        for stage, nbytes, e0, e1 in prof_hbm:
+            a = hbm.setdefault(stage, [0.0, 0.0, 0])
+            a[0] += nbytes; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
         dom = max(agg.items(), key=lambda kv: kv[1][1]) if agg else None
         conv_t = sum(v[1] for v in agg.values()); conv_f = sum(v[0] for v in agg.values())
         roof = None
@@ -307,9 +354,13 @@ def main():
             traffic = pmc_traffic_for(label, table)
             if traffic is None:
                 note('WARNING: no PMC traffic row for the dominant kernel %s in %s' % (label, src))
+            meta = pmc_traffic_meta(src)
+            now = csrc_sha1()
             roof = {'bound': 'mfma', 'kernel': label, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    'traffic': traffic, 'traffic_source': src,
+                    'traffic': traffic, 'traffic_source': src, 'traffic_git_commit': meta.get('git_commit'),
+                    'traffic_csrc_sha1': meta.get('csrc_sha1'), 'csrc_sha1': now,
+                    'traffic_stale': (meta.get('csrc_sha1') != now) if meta.get('csrc_sha1') else None,
                     'launches': cnt, 'avg_launch_ms': round(tt / cnt * 1e3, 4),
                     'all_mfma_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'time_frac_of_step': round(v[1] / dt, 4),
                                              'launches': v[2]} for k, v in sorted(agg.items())},
@@ -322,12 +373,33 @@ def main():
             'config': {'workload': 'UNet_R_SS_v2 generator + SRGAN-style discriminator, one G+D step (train_seg_gan.py:182-233), '
                                    '%d x 3x%dx%d tiles per GPU, fp32, Adam lr 2e-5' % (args.batch, args.size, args.size),
                        'global_batch': args.batch * world, 'tile': args.size,
-                       'parallelism': 'dp%d%s' % (world, ' (RCCL grad all-reduce + sync-BN)' if world > 1 else ''),
+                       'parallelism': 'dp%d%s' % (world, ' (RCCL grad all-reduce + sync-BN)' if S.dp.is_dist() else ''),
                        'dead_d_param_grads_of_g_step': 'computed' if D_PASSES == 9 else 'not computed (zeroed unread in the reference, train_seg_gan.py:225)'},
-            'backend': backend, 'devices': devices,
+            'backend': backend if backend else (dist.get_backend() if S.dp.is_dist() else None), 'devices': devices,
             'loss': round(float(out[0]), 6), 'iou': round(float(out[1]), 6), 'dice': round(float(out[2]), 6),
             'roofline': roof,
         }
+        # north-star sub-metrics (BASELINE.json): MFMA roofline on the 3x3 encoder convs; achieved HBM rate on the memory-bound
+        # stages -- algorithmic bytes of SURVEY.md 8(d) / HIP-event time on the launch stream, against the 8 TB/s spec
+        if enc[2]:
+            line['encoder_3x3'] = {'flops_per_step': round(enc[0] / args.steps), 'launches_per_step': enc[2] // args.steps,
+                                   'ms_per_step': round(enc[1] / args.steps * 1e3, 3), 'tflops': round(enc[0] / enc[1] / 1e12, 2),
+                                   'frac': round(enc[0] / enc[1] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   'algorithmic_gmac_per_img': ENCODER_3X3_GMAC_PER_IMG_512 * (args.size / 512.0) ** 2}
+        if hbm:
+            line['hbm_stages'] = {k: {'gbytes_per_step': round(v[0] / args.steps / 1e9, 3), 'ms_per_step': round(v[1] / args.steps * 1e3, 3),
+                                      'launches_per_step': v[2] // args.steps, 'tbps': round(v[0] / v[1] / 1e12, 3),
+                                      'frac_of_8tbps': round(v[0] / v[1] / 8e12, 4)} for k, v in sorted(hbm.items())}
+        if prof_comm:
+            # the sync-BN statistics all-reduces sit on the compute stream between the two stages of every batch norm: their
+            # event time is stream time the step cannot overlap (measured, not estimated)
+            comm = {}
+            for kind, nbytes, e0, e1 in prof_comm:
+                a = comm.setdefault(kind, [0, 0.0, 0])
+                a[0] += nbytes; a[1] += e0.elapsed_time(e1); a[2] += 1
+            line['sync_bn_allreduce'] = {k: {'per_step': v[2] // args.steps, 'ms_per_step': round(v[1] / args.steps, 3),
+                                             'avg_us': round(v[1] / v[2] * 1e3, 1), 'avg_bytes': v[0] // v[2]} for k, v in sorted(comm.items())}
+            line['sync_bn_allreduce_ms'] = round(sum(v[1] for v in comm.values()) / args.steps, 3)
         if buckets is not None:
             line['grad_bucket_allreduce'] = buckets
         if world == 1:
@@ -335,8 +407,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_available() and dist.is_initialized():          # also the world-1 rehearsal under SSG_DIST_FORCE=1
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

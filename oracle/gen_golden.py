@@ -11,7 +11,7 @@ are the reference's.
 
 Fixtures carry seeds + inputs + outputs (+ per-parameter digests), never weights or code.
 
-    python oracle/gen_golden.py [--only step64|step256|blocks]
+    python oracle/gen_golden.py [--only step64|step256|blocks|dp|...]
 """
 import argparse
 import os
@@ -428,6 +428,40 @@ def gen_effb4(mods):
     print('effb4_n4_1024.npz written; feature digest', data['feat_digest'])
 
 
+def gen_dp(mods, world=2, b=2, h=64, w=64, steps=2):
+    """Data-parallel oracle ("sync-BN-at-W == single-process batch W*b"): the reference's modules in ONE
+    process on the concatenated batch of W ranks, every BatchNorm2d converted by the reference's own `batchnorm.convert_model`
+    to its SynchronizedBatchNorm2d and run through that class's parallel-training branch (batchnorm.py:57-80) with the statistics
+    of the whole batch handed to ITS `_compute_mean_std` (batchnorm.py:115-127: biased variance clamped at eps for the
+    normalisation, unbiased variance into the running estimate).  Only the device transport between the replicas
+    (`SyncMaster.run_master` -> ReduceAddCoalesced / Broadcast, comm.py + batchnorm.py:92-113: CUDA-only, and the identity
+    for a single contributor) is replaced by a direct call.  The step sequence is ref_step (train_seg_gan.py:182-233)."""
+    import batchnorm as ref_bn
+    G, D, _, _ = ref_models(mods)
+    G = ref_bn.convert_model(G); D = ref_bn.convert_model(D)
+    nconv = 0
+    for m in list(G.modules()) + list(D.modules()):
+        if isinstance(m, ref_bn._SynchronizedBatchNorm):
+            m._is_parallel = True; m._parallel_id = 0
+            m._sync_master.run_master = (lambda mod: (lambda msg: mod._compute_mean_std(msg.sum, msg.ssum, msg.sum_size)))(m)
+            nconv += 1
+    og = torch.optim.Adam(params=filter(lambda p: p.requires_grad, G.parameters()), lr=2e-5)
+    od = torch.optim.Adam(params=filter(lambda p: p.requires_grad, D.parameters()), lr=2e-5)
+    n = world * b
+    inp, tgt = synthetic_batch(n, h, w)
+    data = dict(seed_model=np.array(41), seed_batch=np.array(7), shape=np.array([n, 3, h, w]), world=np.array(world),
+                n_sync_bn=np.array(nconv), input=inp.numpy(), target=tgt.numpy(),
+                param_names_G=np.array([k for k, _ in G.named_parameters()]),
+                param_names_D=np.array([k for k, _ in D.named_parameters()]))
+    for s in range(steps):
+        rec = {}
+        ref_step(mods, G, D, og, od, inp, tgt, rec)
+        for k, v in rec.items():
+            data['s%d_%s' % (s, k)] = v
+        print('step_dp', 'step', s, rec['scalars'])
+    np.savez_compressed(os.path.join(OUT, 'step_dp_w%d_n%d_%d.npz' % (world, n, h)), **data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
@@ -451,6 +485,8 @@ def main():
         gen_step(mods, 'step_n4_256', 4, 256, 256, steps=1, keep_logits=False)
     if a.only in (None, 'stepsn'):
         gen_step_sn(mods)
+    if a.only in (None, 'dp'):
+        gen_dp(mods)
     if a.only == 'effb4':
         gen_effb4(mods)                 # ~15 GB RSS, a minute of the reference on 8 cores: on request only
     if a.only == 'step512':

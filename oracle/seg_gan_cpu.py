@@ -29,9 +29,12 @@ class ActivationPattern(object):
                      implementation was on).
     With PATTERN = None (the default) every op is the stock torch op: fixtures and the CPU baseline are unaffected."""
 
-    def __init__(self, mode, items=None):
+    def __init__(self, mode, items=None, keep=False):
         assert mode in ('record', 'impose')
         self.mode, self.items, self.pos = mode, (items if items is not None else []), 0
+        # impose + keep: `seen` receives, in call order, the pre-activation (act) / pool input this run computed at each decision
+        # while it FOLLOWED the imposed pattern up to there -- so a decision can be checked given identical upstream decisions
+        self.keep, self.seen = keep, []
 
 
 PATTERN = None
@@ -45,6 +48,8 @@ def _act(x, slope=0.0):
         return F.relu(x) if slope == 0.0 else F.leaky_relu(x, slope)
     m = P.items[P.pos]; P.pos += 1
     assert m.shape == x.shape, 'activation pattern out of step: %s vs %s' % (tuple(m.shape), tuple(x.shape))
+    if P.keep:
+        P.seen.append(x.detach().clone())
     return torch.where(m, x, x * slope)
 
 
@@ -73,6 +78,8 @@ class _MaxPoolIdx(nn.Module):
                 P.items.append(('pool', x.detach().clone(), idx.clone()))
             return y, idx
         win = P.items[P.pos]; P.pos += 1
+        if P.keep:
+            P.seen.append(x.detach().clone())
         n, c, h, w = x.shape
         assert win.shape == (n, c, h // 2, w // 2)
         xs = x.unfold(2, 2, 2).unfold(3, 2, 2).reshape(n, c, h // 2, w // 2, 4)
@@ -328,6 +335,42 @@ def make_models(seed=41, num_classes=3):
     opt_g = torch.optim.Adam(filter(lambda p: p.requires_grad, G.parameters()), lr=2e-5)
     opt_d = torch.optim.Adam(filter(lambda p: p.requires_grad, D.parameters()), lr=2e-5)
     return G, D, opt_g, opt_d
+
+
+class SyncBatchNorm2dCPU(nn.BatchNorm2d):
+    """batchnorm.py:40-127 (`_SynchronizedBatchNorm`) for W replicas evaluated in ONE process on the concatenated batch: the
+    parallel-training branch (:57-80) with the whole batch's sums handed to `_compute_mean_std` (:115-127) --
+    mean = sum/n, inv_std = clamp((ssum - sum*mean)/n, eps)^-1/2, running_var <- unbiased (n-1) estimate.  Eval mode is the
+    stock batch norm (:52-55).  Pinned by tests/golden/step_dp_w2_n4_64.npz (oracle/gen_golden.py --only dp)."""
+
+    def forward(self, x):
+        if not self.training:
+            return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, self.momentum, self.eps)
+        shp = x.shape
+        x = x.reshape(shp[0], self.num_features, -1)                            # :58-59
+        size = x.size(0) * x.size(2)                                            # :62
+        sum_ = x.sum(dim=0).sum(dim=-1); ssum = (x ** 2).sum(dim=0).sum(dim=-1)  # :63-64 (_sum_ft)
+        assert size > 1                                                         # :118
+        mean = sum_ / size; sumvar = ssum - sum_ * mean                         # :119-120
+        unbias_var = sumvar / (size - 1); bias_var = sumvar / size              # :121-122
+        self.running_mean = (1 - self.momentum) * self.running_mean + self.momentum * mean.data     # :124
+        self.running_var = (1 - self.momentum) * self.running_var + self.momentum * unbias_var.data  # :125
+        inv_std = bias_var.clamp(self.eps) ** -0.5                              # :127
+        y = (x - mean.view(1, -1, 1)) * (inv_std * self.weight).view(1, -1, 1) + self.bias.view(1, -1, 1)   # :75
+        return y.view(shp)
+
+
+def convert_sync_batchnorm(module):
+    """batchnorm.py:320-360 (`convert_model`): every BatchNorm2d -> the synchronised class, parameters and statistics carried over."""
+    mod = module
+    if isinstance(module, nn.BatchNorm2d) and not isinstance(module, SyncBatchNorm2dCPU):
+        mod = SyncBatchNorm2dCPU(module.num_features, module.eps, module.momentum, module.affine)
+        mod.running_mean = module.running_mean; mod.running_var = module.running_var
+        if module.affine:
+            mod.weight.data = module.weight.data.clone().detach(); mod.bias.data = module.bias.data.clone().detach()
+    for name, child in module.named_children():
+        mod.add_module(name, convert_sync_batchnorm(child))
+    return mod
 
 
 def synthetic_batch(n, h, w, seed=7, num_classes=3):

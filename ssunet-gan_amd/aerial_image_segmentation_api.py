@@ -55,6 +55,29 @@ def patch_gen(img, mask, p_size, overlap=0.5):
 _GRAPHS = {}
 
 
+def _cached_operands(model):
+    """Every tensor the packed-weight (`ops._pack`, `bf16._pack`), BN-fold (`BasicBlock._folded`) and gamma|beta-concat
+    (`blocks._spade_cat`) caches of `model` hold right now."""
+    held = []
+    for t in list(model.parameters()) + list(model.buffers()):
+        for name in ('_ssg_pack', '_ssg_pack_bf16'):
+            c = t.__dict__.get(name)
+            if c is not None:
+                held += list(c[1].values())
+        c = t.__dict__.get('_ssg_gb_cat')
+        if c is not None:
+            held += [c[1], c[2]]
+    for m in model.modules():
+        c = getattr(m, '_fold_cache', None)
+        if c is not None:
+            held += list(c[1])
+            for t in c[1]:                       # the folded weights are themselves packed per use
+                p = t.__dict__.get('_ssg_pack')
+                if p is not None:
+                    held += list(p[1].values())
+    return held
+
+
 def _graph_for(model, shape, device):
     """hipGraph of `sigmoid(model(x))` for one input shape (eval mode), captured after a warm-up call that fills the
     packed-weight and BN-fold caches; tied to the parameter values it was captured with (keyed by the weight / statistics
@@ -63,10 +86,15 @@ def _graph_for(model, shape, device):
     so); the deep levels do (16x16 x 768 channels at batch 1 is 12 workgroups of 432 K-steps on a 256-CU chip).  The graph
     path is therefore opt-in (`graph=True`), kept because it takes the Python launch path off the host for callers that
     overlap other host work."""
-    key = (id(model), tuple(shape), str(device), ops._WEIGHT_EPOCH[0], ops._STATS_EPOCH[0])
+    # The capture bakes in the ADDRESSES of the packed-weight / BN-fold tensors the warm-up call cached, so it is valid for
+    # exactly one state of every parameter and buffer: (storage address, autograd version) of each -- what the caches themselves
+    # stamp with -- plus the two epochs that cover raw-pointer writes.  load_state_dict() / any in-place edit changes a version
+    # and forces a new capture instead of replaying the old weights (ADVICE r2).
+    stamp = tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
+    key = (id(model), tuple(shape), str(device), ops._WEIGHT_EPOCH[0], ops._STATS_EPOCH[0], hash(stamp))
     hit = _GRAPHS.get(key)
-    if hit is not None and hit[0]() is model:
-        return hit[1:]
+    if hit is not None and hit[0]() is model and hit[4] == stamp:
+        return hit[1:4]
     import weakref
     static_in = torch.zeros(shape, dtype=torch.float32, device=device)
     side = torch.cuda.Stream(device=device)
@@ -79,7 +107,9 @@ def _graph_for(model, shape, device):
         static_out = ops.sigmoid(model(static_in))
     for k in [k for k, v in _GRAPHS.items() if v[0]() is None or (k[0] == id(model) and k[1] == tuple(shape))]:
         del _GRAPHS[k]                                  # stale captures of this model / dead models
-    _GRAPHS[key] = (weakref.ref(model), graph, static_in, static_out)
+    # keep what the captured kernels read alive for as long as the capture: a later eager forward with other weights
+    # re-fills the caches and would otherwise free these tensors under the graph
+    _GRAPHS[key] = (weakref.ref(model), graph, static_in, static_out, stamp, _cached_operands(model))
     return graph, static_in, static_out
 
 

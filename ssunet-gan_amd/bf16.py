@@ -181,33 +181,39 @@ def conv1x1(x, weight):
 # ----------------------------------------------------------------------------- batch norm (+ swish | + residual)
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, res, eps, momentum, act):
+    def forward(ctx, x, weight, bias, running_mean, running_var, res, eps, momentum, act, var_mode, group):
         ldx = _ld(x)
         n, c, h, w = x.shape
         p = n * h * w
         dev = x.device
         if res is not None:
             _ld(res)
+        # synchronised statistics (BASELINE config 4 "on 8 x MI355X"): exactly ops._bn_fwd_impl -- the fp64 [sum, sum^2, pixel
+        # count] vector is all-reduced between the two stages, the reference's sync formula clamp(var, eps)^-1/2 (var_mode 1)
+        synced = ops._synced(group)
         ws = ops._ws(call('ssg_bn_workspace_bytes', p, c), dev)
         sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-        call('ssg_bn_stats_bf16', ptr(x), p, c, ldx, ptr(sums), 0, ptr(ws), stream_ptr())
+        call('ssg_bn_stats_bf16', ptr(x), p, c, ldx, ptr(sums), int(synced), ptr(ws), stream_ptr())
+        if synced:
+            ops._timed_all_reduce('sync_bn_fwd', sums, group)
         stats = torch.empty((4, c), dtype=torch.float32, device=dev)
-        call('ssg_bn_finalize_f32', ptr(sums), float(p), c, ptr(weight), ptr(bias), eps, momentum, 0, ptr(running_mean), ptr(running_var),
-             ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), stream_ptr())
+        call('ssg_bn_finalize_f32', ptr(sums), 0.0 if synced else float(p), c, ptr(weight), ptr(bias), eps, momentum, var_mode,
+             ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), stream_ptr())
         if running_mean is not None or running_var is not None:
             ops._STATS_EPOCH[0] += 1
         y = new_bf16(n, c, h, w, dev)
         call('ssg_bn_apply_bf16', ptr(x), p, c, ldx, ptr(stats[2]), ptr(stats[3]), ptr(res), c if res is not None else 0, act, 0.0,
              ptr(y), c, stream_ptr())
         ctx.save_for_backward(x, weight, stats)
-        ctx.cfg = (act, res is not None)
+        ctx.cfg = (act, res is not None, group if synced else None)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, weight, stats = ctx.saved_tensors
-        act, has_res = ctx.cfg
+        act, has_res, group = ctx.cfg
+        synced = group is not None
         dy = as_bf16(dy)
         n, c, h, w = x.shape
         p = n * h * w
@@ -215,13 +221,18 @@ class _BNAct(torch.autograd.Function):
         ws = ops._ws(call('ssg_bn_workspace_bytes', p, c), dev)
         sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
         call('ssg_bn_bwd_reduce_bf16', ptr(x), None, ptr(dy), p, c, c, 0, c, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
-             act, 0.0, ptr(sums), 0, ptr(ws), stream_ptr())
+             act, 0.0, ptr(sums), int(synced), ptr(ws), stream_ptr())
+        local = sums.clone() if synced else sums          # this rank's weight / bias gradients; data-parallel averages them later
+        if synced:
+            ops._timed_all_reduce('sync_bn_bwd', sums, group)
         dwb = torch.empty((2, c), dtype=torch.float32, device=dev)
         dx = new_bf16(n, c, h, w, dev)
         call('ssg_bn_bwd_apply_bf16', ptr(x), None, ptr(dy), p, c, c, 0, c, ptr(stats[0]), ptr(stats[1]), ptr(weight), ptr(stats[2]), ptr(stats[3]),
-             ptr(sums), float(p), act, 0.0, ptr(dx), c, None, 0, ptr(dwb[0]), ptr(dwb[1]), stream_ptr())
+             ptr(sums), 0.0 if synced else float(p), act, 0.0, ptr(dx), c, None, 0, ptr(dwb[0]), ptr(dwb[1]), stream_ptr())
+        if synced:
+            dwb = torch.stack([local[c:2 * c], local[:c]]).float()
         dres = dy if (has_res and ctx.needs_input_grad[5]) else None         # no activation after the residual add (model.py:93-97)
-        return dx, dwb[0], dwb[1], None, None, dres, None, None, None
+        return dx, dwb[0], dwb[1], None, None, dres, None, None, None, None, None
 
 
 class _Affine(torch.autograd.Function):
@@ -248,12 +259,13 @@ def batch_norm_act(x, bn, res=None, act=ACT_NONE):
     if bn.training or not bn.track_running_stats:
         if bn.momentum is None:
             raise NotImplementedError('cumulative-average batch norm (momentum=None)')
-        if getattr(bn, '_ssg_sync_group', None) is not None:
-            raise NotImplementedError('synchronized batch norm on the bf16 path')
-        if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        group = getattr(bn, '_ssg_sync_group', None)          # dp.convert_sync_batchnorm
+        if bn.track_running_stats and bn.num_batches_tracked is not None and not ops._synced(group):
+            bn.num_batches_tracked.add_(1)           # the reference's synchronised branch never counts batches (batchnorm.py:57-80)
+        var_mode = getattr(bn, '_ssg_var_mode', 1 if group is not None else 0)
         return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                            bn.running_var if bn.track_running_stats else None, res, float(bn.eps), float(bn.momentum), int(act))
+                            bn.running_var if bn.track_running_stats else None, res, float(bn.eps), float(bn.momentum), int(act),
+                            int(var_mode), group)
     with torch.no_grad():
         scale = torch.rsqrt(bn.running_var + bn.eps) * bn.weight
         shift = bn.bias - bn.running_mean * scale

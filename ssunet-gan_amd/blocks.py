@@ -71,7 +71,8 @@ class _BasicBlockFn(torch.autograd.Function):
 def basic_block(x1, x2, conv1, bn1, conv2, bn2, shortcut_conv, group=None):
     """Fused training-mode BasicBlock over nn.Conv2d / nn.BatchNorm2d parameter holders."""
     for bn in (bn1, bn2):
-        if bn.track_running_stats and bn.num_batches_tracked is not None:
+        # the reference's synchronised branch never touches num_batches_tracked (batchnorm.py:57-80); its stock branch does
+        if bn.track_running_stats and bn.num_batches_tracked is not None and not ops._synced(group):
             bn.num_batches_tracked.add_(1)
     var_mode = getattr(bn1, '_ssg_var_mode', 1 if group is not None else 0)
     return _BasicBlockFn.apply(x1, x2, conv1.weight, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
@@ -143,7 +144,8 @@ class _SpadeFn(torch.autograd.Function):
         gb = _spade_fused_fwd(x, a, wgb, bgb, pad, out)           # gamma only ([n, c, h, w]) when the fused kernel took it
         if gb is None:
             gb = _conv_fwd_impl(a, None, wgb, bgb, 1, pad, ACT_NONE, 0.0)
-            call('ssg_spade_modulate_fwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), n * h * w, c, ptr(out), _ld(out), stream_ptr())
+            with ops._hbm('spade_modulate_fwd', 16.0 * n * h * w * c):           # x, gamma, beta in; out (3 reads + 1 write)
+                call('ssg_spade_modulate_fwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), n * h * w, c, ptr(out), _ld(out), stream_ptr())
         ctx.save_for_backward(x, seg, a, gb, wx, ws, wgb)
         ctx.pad = pad
         return out
@@ -160,8 +162,10 @@ class _SpadeFn(torch.autograd.Function):
         # modulate backward and the gamma / beta bias gradients (column sums of dgb) in one pass over the data
         scratch = ops._ws(call('ssg_bn_workspace_bytes', n * h * w, c), x.device)
         sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
-        call('ssg_spade_modulate_bwd_sums_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), ptr(dout), _ld(dout), n * h * w, c,
-             ptr(dxm), _ld(dxm), ptr(dgb), _ld(dgb), ptr(sums), ptr(scratch), stream_ptr())
+        # x, gamma (|beta where the conv wrote both), dout in; dx, d(gamma), d(beta) out
+        with ops._hbm('spade_modulate_bwd', 4.0 * n * h * w * c * (3 + 3)):
+            call('ssg_spade_modulate_bwd_sums_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), ptr(dout), _ld(dout), n * h * w, c,
+                 ptr(dxm), _ld(dxm), ptr(dgb), _ld(dgb), ptr(sums), ptr(scratch), stream_ptr())
         dwgb = _conv_wgrad_impl(a, None, dgb, wgb.shape, 1, pad)
         dbias_gb = sums.float()
         nh = a.shape[1]

@@ -33,22 +33,28 @@ void ssg_conv_halo_tile(int halo_variant, int* th, int* tw, int* bn);
 int ssg_conv_halo_ksplit(const ConvArgs& a, int variant);    // split-K slabs the launch would use given a workspace (1 = none)
 
 // Batch-norm statistics in the conv epilogue (halo and DMA kernels): every lane adds up its output column over the rows it
-// holds (fp32, <= 32 values), the partials are widened to fp64, folded over the two lane halves and the WAVES_M waves, and
-// one row [2][Cout-slice] per workgroup goes to a.bnpart; ssg_bn_stats_from_partials_f32 adds the rows in order.
-template <int NI, int WAVES_M, int BN, int WTN>
-__device__ __forceinline__ void ssg_bnpart_store(const ConvArgs& a, float* lds_f, const float (&s1)[NI], const float (&s2)[NI], int mtile, int n0,
-                                                 int wm, int wn, int half, int l31) {
-  double* red = (double*)lds_f;                  // [WAVES_M][2][BN]
-  __syncthreads();                               // the K loop's LDS tiles are dead for every wave
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    double d1 = (double)s1[j], d2 = (double)s2[j];
-    d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
-    if (half == 0) {
-      red[(wm * 2 + 0) * BN + wn * WTN + j * 32 + l31] = d1;
-      red[(wm * 2 + 1) * BN + wn * WTN + j * 32 + l31] = d2;
-    }
+// holds (<= 32 values) as fp32 deviations from a pivot, converted to fp64 sums of the values once per column (see the
+// kernels: fp32 sums of the raw values lose var = E[x^2] - mean^2 when |mean| >> std); the fp64 partials are folded over the
+// two lane halves and the WAVES_M waves, and one row [2][Cout-slice] per workgroup goes to a.bnpart;
+// ssg_bn_stats_from_partials_f32 adds the rows in order.
+// One column fragment j of one wave: (fp32 deviation sums s1, s2 around pivot `piv` over `nv` rows) -> fp64 sums of the values,
+// folded over the two lane halves, into the LDS scratch [WAVES_M][2][BN].  Call between ssg_bnpart_begin and ssg_bnpart_finish.
+template <int BN, int WTN>
+__device__ __forceinline__ void ssg_bnpart_put(float* lds_f, int j, float s1, float s2, float piv, int nv, int wm, int wn, int half, int l31) {
+  double* red = (double*)lds_f;
+  const double c = (double)piv, n = (double)nv;
+  double d1 = (double)s1 + n * c;
+  double d2 = (double)s2 + 2.0 * c * (double)s1 + n * c * c;
+  d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
+  if (half == 0) {
+    red[(wm * 2 + 0) * BN + wn * WTN + j * 32 + l31] = d1;
+    red[(wm * 2 + 1) * BN + wn * WTN + j * 32 + l31] = d2;
   }
+}
+__device__ __forceinline__ void ssg_bnpart_begin() { __syncthreads(); }      // the K loop's LDS tiles are dead for every wave
+template <int NI, int WAVES_M, int BN, int WTN>
+__device__ __forceinline__ void ssg_bnpart_finish(const ConvArgs& a, float* lds_f, int mtile, int n0, int wm, int wn, int half, int l31) {
+  double* red = (double*)lds_f;
   __syncthreads();
   if (wm == 0 && half == 0) {
 #pragma unroll

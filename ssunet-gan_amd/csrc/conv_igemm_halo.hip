@@ -252,13 +252,17 @@ __device__ __forceinline__ void halo_body(const ConvArgs& a) {
     return;
   }
   const bool want_bn = a.bnpart != nullptr;
-  float bn1[NI], bn2[NI];
+  if (want_bn) ssg_bnpart_begin();
+  // Column sums for the batch-norm statistics.  var = E[x^2] - mean^2 cancels, so plain fp32 partials lose it once |mean| >> std
+  // (ADVICE r2).  Each lane sums DEVIATIONS from a pivot (its first output of the column) in fp32 -- their rounding error is
+  // relative to |v - pivot|, not |v| -- and converts to sums of v in fp64 once per column: S1 = s1 + n*c, S2 = s2 + 2*c*s1 + n*c^2.
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn * WTN + j * 32 + l31;
     const bool cok = co < a.Cout;
     const float bv = (a.bias && cok) ? a.bias[co] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f; int nv = 0;
+    const float piv = acc[0][j][0] + bv;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -268,7 +272,7 @@ __device__ __forceinline__ void halo_body(const ConvArgs& a) {
         if (gy < a.GH && gx < a.GW) {
           const size_t pix = ((size_t)(n * a.OH + gy * a.out_sy + a.out_oy) * a.OW + gx * a.out_sx + a.out_ox);
           float v = acc[i][j][r] + bv;
-          if (want_bn) { s1 += v; s2 += v * v; }
+          if (want_bn) { const float dv = v - piv; s1 += dv; s2 += dv * dv; ++nv; }
           if (cok) {
             if (a.res) v += a.res[pix * a.ldr + co];
             if (a.act == SSG_ACT_RELU) v = v < 0.f ? 0.f : v;
@@ -280,13 +284,16 @@ __device__ __forceinline__ void halo_body(const ConvArgs& a) {
         }
       }
     }
-    bn1[j] = s1; bn2[j] = s2;
+    if (want_bn) ssg_bnpart_put<BN, WTN>(lds, j, s1, s2, piv, nv, wm, wn, half, l31);
   }
-  if (want_bn) ssg_bnpart_store<NI, WAVES_M, BN, WTN>(a, lds, bn1, bn2, (n * a.tiles_y + ty) * a.tiles_x + tx, n0, wm, wn, half, l31);
+  if (want_bn) ssg_bnpart_finish<NI, WAVES_M, BN, WTN>(a, lds, (n * a.tiles_y + ty) * a.tiles_x + tx, n0, wm, wn, half, l31);
 }
 
+// second launch bound = waves per SIMD of the 3 (4 for <128,64>) workgroups per CU the LDS footprint is sized for: the pivoted
+// statistics of the epilogue cost 4 registers and the allocator would otherwise trade a resident workgroup for them
+// (<128,128> sat at 167 of 168)
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_halo_kernel(const ConvArgs a) { halo_body<BM, BN, WAVES_M, WAVES_N, 5, false>(a); }
+__global__ __launch_bounds__(256, (BN == 128 || BM == 256) ? 3 : 4) void conv_igemm_halo_kernel(const ConvArgs a) { halo_body<BM, BN, WAVES_M, WAVES_N, 5, false>(a); }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_halo16_kernel(const ConvArgs a) { halo_body<BM, BN, WAVES_M, WAVES_N, 4, false>(a); }

@@ -177,6 +177,58 @@ def _fill_taps(desc, taps):
 # start event, end event) for every MFMA conv launch, recorded on the launch stream.
 PROFILE = None
 PROFILE_SHAPES = False      # debug: append the launch geometry to the label
+# bench.py's north-star sub-metrics (BASELINE.json: "MFMA roofline on the 3x3 encoder convs", "achieved HBM GB/s on the
+# memory-bound upsample/BN stages"): while PROFILE is a list, PROFILE_HBM receives (stage, algorithmic bytes per SURVEY.md 8(d),
+# start event, end event) for every launch group of the memory-bound stages, and every MFMA record carries the ROLE the model
+# code set around the launch (archs.UNet_R_SS_v2 tags the forward 3x3 convs of its six encoder BasicBlocks 'encoder_3x3').
+PROFILE_HBM = None
+PROFILE_COMM = None         # (kind, bytes, start event, end event) per small collective on the compute stream (sync-BN statistics)
+_ROLE = [None]
+
+
+def _timed_all_reduce(kind, t, group):
+    """dist.all_reduce(SUM) of a sync-BN statistics vector, with HIP events on the launch stream while bench.py profiles: the
+    collective is stream-ordered on the compute stream's critical path, so event time = what it costs the step."""
+    if PROFILE_COMM is None:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    e1.record(torch.cuda.current_stream())
+    PROFILE_COMM.append((kind, t.numel() * t.element_size(), e0, e1))
+
+
+class role(object):
+    """with ops.role('encoder_3x3'): ...   -- labels the forward conv launches issued inside (profiling only)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = _ROLE[0]; _ROLE[0] = self.name
+
+    def __exit__(self, *a):
+        _ROLE[0] = self.prev
+
+
+class _hbm(object):
+    """HIP events on the launch stream around one memory-bound stage (no-op unless bench.py profiles)."""
+
+    def __init__(self, stage, nbytes):
+        self.rec = PROFILE_HBM is not None
+        if self.rec:
+            self.stage, self.nbytes = stage, float(nbytes)
+            self.e0 = torch.cuda.Event(enable_timing=True); self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.rec:
+            self.e0.record(torch.cuda.current_stream())
+
+    def __exit__(self, *a):
+        if self.rec:
+            self.e1.record(torch.cuda.current_stream())
+            PROFILE_HBM.append((self.stage, self.nbytes, self.e0, self.e1))
 
 
 _CONV_LABELS = {0: 'conv_igemm_kernel<128,128>', 1: 'conv_igemm_kernel<256,64>', 2: 'conv_igemm_kernel<256,32>',
@@ -192,10 +244,10 @@ _WGRAD_LABELS = {0: 'wgrad_kernel<128,128>', 1: 'wgrad_kernel<128,64>', 2: 'wgra
 
 
 class _Timed(object):
-    def __init__(self, label, flops):
+    def __init__(self, label, flops, tag=None):
         self.rec = PROFILE is not None
         if self.rec:
-            self.label, self.flops = label, flops
+            self.label, self.flops, self.tag = label, flops, tag
             self.e0 = torch.cuda.Event(enable_timing=True); self.e1 = torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
@@ -205,11 +257,11 @@ class _Timed(object):
     def __exit__(self, *a):
         if self.rec:
             self.e1.record(torch.cuda.current_stream())
-            PROFILE.append((self.label, self.flops, self.e0, self.e1))
+            PROFILE.append((self.label, self.flops, self.e0, self.e1, self.tag))
 
 
 def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps, n, h, w, gh, gw, oh, ow,
-                 in_s, out_s, out_oy, out_ox, out, want_bn=False):
+                 in_s, out_s, out_oy, out_ox, out, want_bn=False, tag=None):
     """Returns None, or -- with want_bn and a kernel that has the statistics epilogue -- the fp64 tensor [rows, 2, cout] of
     per-tile (sum, sum of squares) of the conv output (ssg_conv_desc.bnpart)."""
     d = ConvDesc()
@@ -252,7 +304,7 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
         label = _CONV_LABELS.get(call('ssg_conv2d_kernel_id', C.byref(d)), '?') + ('+splitk' if ws is not None else '')
         if PROFILE_SHAPES:
             label += ' n%d %dx%d cin%d cout%d taps%d s%d/%d' % (n, gh, gw, cred, cout, len(taps), in_s, out_s)
-    with _Timed(label, 2.0 * n * gh * gw * cout * cred * len(taps)):
+    with _Timed(label, 2.0 * n * gh * gw * cout * cred * len(taps), tag):
         call('ssg_conv2d_f32', C.byref(d), stream_ptr())
     return part
 
@@ -288,7 +340,8 @@ def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=
     if out is None:
         out = new_nhwc(n, o, oh, ow, x1.device)
     part = _conv_launch(x1, x2, wpk, kp, kmode, 0, o, bias, res, act, slope, taps, n, h, w, oh, ow, oh, ow, stride, 1, 0, 0, out,
-                        want_bn=want_bn and res is None and act == ACT_NONE)
+                        want_bn=want_bn and res is None and act == ACT_NONE,
+                        tag=_ROLE[0] if (kh == 3 and kw == 3 and _ROLE[0] is not None) else None)
     return (out, part) if want_bn else out
 
 
@@ -509,6 +562,15 @@ _STATS_EPOCH = [0]
 
 
 def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part=None):
+    """Timed wrapper (bench.py `hbm_stages`): algorithmic bytes per SURVEY.md 8(d) -- 2 reads + 1 write of the tensor, one read
+    less when the statistics rode the producing conv's epilogue, one more for a residual."""
+    n, c, h, w = x.shape
+    reads = (1 if (part is not None and part.numel() > 0) else 2) + (1 if res is not None else 0)
+    with _hbm('bn_fwd', 4.0 * n * h * w * c * (reads + 1)):
+        return _bn_fwd_body(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part)
+
+
+def _bn_fwd_body(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part=None):
     """stats -> (all-reduce) -> finalize -> apply.  Returns (y, stats[4,C], count): `count` is None for a local batch norm
     and, when synchronised, the fp64[1] device tensor holding the all-reduced pixel count (ranks may hold unequal batches:
     the count travels with the sums instead of being assumed to be p * world)."""
@@ -530,7 +592,7 @@ def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum,
         ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
         call('ssg_bn_stats_f32', ptr(x), p, c, _ld(x), ptr(sums), int(synced), ptr(ws), stream_ptr())
     if synced:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        _timed_all_reduce('sync_bn_fwd', sums, group)
     stats = torch.empty((4, c), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
     call('ssg_bn_finalize_f32', ptr(sums), 0.0 if synced else float(p), c, ptr(weight), ptr(bias), eps, momentum, var_mode,
          ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), stream_ptr())
@@ -543,6 +605,14 @@ def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum,
 
 
 def _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, count, want_dres, want_dx=True, had_res=True):
+    """Timed wrapper (bench.py `hbm_stages`): algorithmic bytes per SURVEY.md 8(d) -- 3 reads + 1 write (x, dy, the mask source;
+    dx), plus the dres write where the forward had a residual."""
+    n, c, h, w = x.shape
+    with _hbm('bn_bwd', 4.0 * n * h * w * c * (3 + (1 if want_dx else 0) + (1 if want_dres else 0))):
+        return _bn_bwd_body(x, y, dy, weight, stats, act, slope, group, count, want_dres, want_dx, had_res)
+
+
+def _bn_bwd_body(x, y, dy, weight, stats, act, slope, group, count, want_dres, want_dx=True, had_res=True):
     """Returns (dx, dres, dweight, dbias).  The activation mask is read from y, or -- when the forward had no
     residual (`had_res=False`) -- recomputed from x with the forward's (scale, shift): y is then not read.
     `count`: what _bn_fwd_impl returned (None = local batch norm)."""
@@ -559,7 +629,7 @@ def _bn_bwd_impl(x, y, dy, weight, stats, act, slope, group, count, want_dres, w
     # local (un-reduced) sums are this rank's weight/bias gradients; data-parallel all-reduces them later
     local = sums.clone() if synced else sums
     if synced:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        _timed_all_reduce('sync_bn_bwd', sums, group)
     dwb = torch.empty((2, c), dtype=torch.float32, device=dev)
     dx = new_nhwc(n, c, h, w, dev) if want_dx else None
     dres = new_nhwc(n, c, h, w, dev) if want_dres else None
@@ -649,8 +719,8 @@ def batch_norm_act(x, bn, res=None, act=ACT_NONE, slope=0.0, group=None, var_mod
     if bn.training or not bn.track_running_stats:
         if bn.momentum is None:
             raise NotImplementedError('cumulative-average batch norm (momentum=None)')
-        if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        if bn.track_running_stats and bn.num_batches_tracked is not None and not _synced(group):
+            bn.num_batches_tracked.add_(1)           # the reference's synchronised branch never counts batches (batchnorm.py:57-80)
         if var_mode is None:
             var_mode = getattr(bn, '_ssg_var_mode', 1 if group is not None else 0)
         return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
@@ -683,7 +753,8 @@ class _MaxPool(torch.autograd.Function):
         oh, ow = h // 2, w // 2
         y = new_nhwc(n, c, oh, ow, x.device)
         idx = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device)
-        call('ssg_maxpool2x2_fwd_f32', ptr(x), n, h, w, c, _ld(x), ptr(y), _ld(y), ptr(idx), stream_ptr())
+        with _hbm('maxpool_fwd', n * h * w * c * (4.0 + 1.0 + 0.25)):        # 1 read + 1/4 write + 1/4 byte index per input element
+            call('ssg_maxpool2x2_fwd_f32', ptr(x), n, h, w, c, _ld(x), ptr(y), _ld(y), ptr(idx), stream_ptr())
         ctx.save_for_backward(idx)
         ctx.hw = (h, w)
         ctx.mark_non_differentiable(idx)
@@ -697,7 +768,8 @@ class _MaxPool(torch.autograd.Function):
         n, c, oh, ow = dy.shape
         h, w = ctx.hw
         dx = new_nhwc(n, c, h, w, dy.device)
-        call('ssg_maxpool2x2_bwd_f32', ptr(dy), _ld(dy), ptr(idx), n, h, w, c, ptr(dx), _ld(dx), stream_ptr())
+        with _hbm('maxpool_bwd', n * h * w * c * (1.0 + 0.25 + 4.0)):
+            call('ssg_maxpool2x2_bwd_f32', ptr(dy), _ld(dy), ptr(idx), n, h, w, c, ptr(dx), _ld(dx), stream_ptr())
         return dx
 
 
@@ -721,7 +793,8 @@ class _MaxPoolSkip(torch.autograd.Function):
         oh, ow = h // 2, w // 2
         y = new_nhwc(n, c, oh, ow, x.device)
         idx = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device)
-        call('ssg_maxpool2x2_fwd_f32', ptr(x), n, h, w, c, _ld(x), ptr(y), _ld(y), ptr(idx), stream_ptr())
+        with _hbm('maxpool_fwd', n * h * w * c * (4.0 + 1.0 + 0.25)):        # 1 read + 1/4 write + 1/4 byte index per input element
+            call('ssg_maxpool2x2_fwd_f32', ptr(x), n, h, w, c, _ld(x), ptr(y), _ld(y), ptr(idx), stream_ptr())
         ctx.save_for_backward(idx)
         ctx.hw = (h, w)
         ctx.mark_non_differentiable(idx)
@@ -738,10 +811,12 @@ class _MaxPoolSkip(torch.autograd.Function):
         n, c, oh, ow = dy.shape
         dx = new_nhwc(n, c, h, w, dy.device)
         if dskip is None:
-            call('ssg_maxpool2x2_bwd_f32', ptr(dy), _ld(dy), ptr(idx), n, h, w, c, ptr(dx), _ld(dx), stream_ptr())
+            with _hbm('maxpool_bwd', n * h * w * c * (1.0 + 0.25 + 4.0)):
+                call('ssg_maxpool2x2_bwd_f32', ptr(dy), _ld(dy), ptr(idx), n, h, w, c, ptr(dx), _ld(dx), stream_ptr())
         else:
             dskip = to_nhwc(dskip)
-            call('ssg_maxpool2x2_bwd_add_f32', ptr(dy), _ld(dy), ptr(idx), ptr(dskip), _ld(dskip), n, h, w, c, ptr(dx), _ld(dx), stream_ptr())
+            with _hbm('maxpool_bwd', n * h * w * c * (1.0 + 0.25 + 4.0 + 4.0)):      # + the skip gradient it adds
+                call('ssg_maxpool2x2_bwd_add_f32', ptr(dy), _ld(dy), ptr(idx), ptr(dskip), _ld(dskip), n, h, w, c, ptr(dx), _ld(dx), stream_ptr())
         return dx
 
 
@@ -759,7 +834,8 @@ class _MaxUnpool(torch.autograd.Function):
         if tuple(idx.shape) != (n, h, w, c) or idx.dtype != torch.uint8:
             raise ValueError('max_unpool2x2: indices %s do not match input %s' % (tuple(idx.shape), tuple(x.shape)))
         y = new_nhwc(n, c, 2 * h, 2 * w, x.device)
-        call('ssg_maxunpool2x2_fwd_f32', ptr(x), _ld(x), ptr(idx), n, 2 * h, 2 * w, c, ptr(y), _ld(y), stream_ptr())
+        with _hbm('unpool_fwd', n * h * w * c * (4.0 + 1.0 + 16.0)):         # 1/4 read + 1/4 byte index + 1 write per output element
+            call('ssg_maxunpool2x2_fwd_f32', ptr(x), _ld(x), ptr(idx), n, 2 * h, 2 * w, c, ptr(y), _ld(y), stream_ptr())
         ctx.save_for_backward(idx)
         return y
 
@@ -770,7 +846,8 @@ class _MaxUnpool(torch.autograd.Function):
         dy = to_nhwc(dy)
         n, c, oh, ow = dy.shape
         dx = new_nhwc(n, c, oh // 2, ow // 2, dy.device)
-        call('ssg_maxunpool2x2_bwd_f32', ptr(dy), _ld(dy), ptr(idx), n, oh, ow, c, ptr(dx), _ld(dx), stream_ptr())
+        with _hbm('unpool_bwd', n * (oh // 2) * (ow // 2) * c * (4.0 + 1.0 + 4.0)):
+            call('ssg_maxunpool2x2_bwd_f32', ptr(dy), _ld(dy), ptr(idx), n, oh, ow, c, ptr(dx), _ld(dx), stream_ptr())
         return dx, None
 
 
@@ -779,7 +856,7 @@ def max_unpool2x2(x, idx):
     return _MaxUnpool.apply(x, idx)
 
 
-def _make_upsample(fwd_name, bwd_name):
+def _make_upsample(fwd_name, bwd_name, stage):
     class _Up(torch.autograd.Function):
         @staticmethod
         def forward(ctx, x):
@@ -788,7 +865,8 @@ def _make_upsample(fwd_name, bwd_name):
             if c % 4:
                 raise ValueError('upsample2x: C %% 4 != 0')
             y = new_nhwc(n, c, 2 * h, 2 * w, x.device)
-            call(fwd_name, ptr(x), n, h, w, c, _ld(x), ptr(y), _ld(y), stream_ptr())
+            with _hbm(stage + '_fwd', n * h * w * c * (4.0 + 16.0)):             # 1/4 read + 1 write per output element
+                call(fwd_name, ptr(x), n, h, w, c, _ld(x), ptr(y), _ld(y), stream_ptr())
             return y
 
         @staticmethod
@@ -797,13 +875,14 @@ def _make_upsample(fwd_name, bwd_name):
             dy = to_nhwc(dy)
             n, c, oh, ow = dy.shape
             dx = new_nhwc(n, c, oh // 2, ow // 2, dy.device)
-            call(bwd_name, ptr(dy), _ld(dy), n, oh // 2, ow // 2, c, ptr(dx), _ld(dx), stream_ptr())
+            with _hbm(stage + '_bwd', n * (oh // 2) * (ow // 2) * c * (16.0 + 4.0)):
+                call(bwd_name, ptr(dy), _ld(dy), n, oh // 2, ow // 2, c, ptr(dx), _ld(dx), stream_ptr())
             return dx
     return _Up
 
 
-_BilinearUp = _make_upsample('ssg_upsample2x_bilinear_fwd_f32', 'ssg_upsample2x_bilinear_bwd_f32')
-_NearestUp = _make_upsample('ssg_upsample2x_nearest_fwd_f32', 'ssg_upsample2x_nearest_bwd_f32')
+_BilinearUp = _make_upsample('ssg_upsample2x_bilinear_fwd_f32', 'ssg_upsample2x_bilinear_bwd_f32', 'bilinear')
+_NearestUp = _make_upsample('ssg_upsample2x_nearest_fwd_f32', 'ssg_upsample2x_nearest_bwd_f32', 'nearest')
 
 
 def upsample2x_bilinear(x):
@@ -853,7 +932,8 @@ class _SpadeModulate(torch.autograd.Function):
         if c % 4 or gb.shape[1] != 2 * c:
             raise ValueError('spade_modulate: x has %d channels, gamma|beta has %d' % (c, gb.shape[1]))
         y = new_nhwc(n, c, h, w, x.device)
-        call('ssg_spade_modulate_fwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), n * h * w, c, ptr(y), _ld(y), stream_ptr())
+        with _hbm('spade_modulate_fwd', 16.0 * n * h * w * c):                   # x, gamma, beta in; out
+            call('ssg_spade_modulate_fwd_f32', ptr(x), _ld(x), ptr(gb), _ld(gb), n * h * w, c, ptr(y), _ld(y), stream_ptr())
         ctx.save_for_backward(x, gb)
         return y
 

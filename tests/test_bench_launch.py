@@ -27,6 +27,27 @@ def test_bench_gpus2_starts_two_ranks_over_gloo():
     assert line['n_gpus'] == 2 and line['backend'] == 'gloo' and line['rank_sum'] == 3.0
 
 
+@pytest.mark.timeout(240)
+def test_bench_gpus8_starts_eight_ranks_over_gloo():
+    """The N = 8 shape of the driver's scaling run (BASELINE config 3), rehearsed on CPU: eight ranks, one process group,
+    one JSON line from rank 0, a destroyed group on every rank (no 'destroy_process_group() was not called' warning)."""
+    r = _run(['--gpus', '8', '--launch-check'], {'SSG_DIST_BACKEND': 'gloo', 'OMP_NUM_THREADS': '1'}, timeout=230)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['backend'] == 'gloo' and line['rank_sum'] == 36.0
+    assert 'destroy_process_group() was not called' not in r.stderr
+
+
+@pytest.mark.timeout(60)
+def test_bench_refuses_to_self_launch_under_a_profiler_preload():
+    """under rocprofv3 the parent has already initialised the GPU; starting the launcher from it is the forbidden
+    exec hop.  bench.py must refuse (exit 2) instead."""
+    r = _run(['--gpus', '2', '--launch-check'], {'SSG_DIST_BACKEND': 'gloo', 'ROCPROF_KERNEL_TRACE': '1'}      )
+    assert r.returncode == 2 and 'refusing to self-launch' in r.stderr
+
+
 @pytest.mark.timeout(60)
 def test_bench_refuses_world_size_mismatch():
     r = _run(['--gpus', '2', '--launch-check'], {'WORLD_SIZE': '1', 'RANK': '0'})

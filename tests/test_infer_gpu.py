@@ -162,3 +162,27 @@ def test_full_size_2048_image_36_patches(pkg, dev, tmp_path):
     assert set(np.unique(all_mask[1])) <= {0, 255} and gt_mask is all_mask
     want = A.patch_merge(full, list(probs12), 1024, config, 0.5)
     assert all(np.array_equal(a, b) for a, b in zip(all_mask, want))
+
+
+@pytest.mark.gpu
+def test_graph_replay_follows_load_state_dict(pkg, dev):
+    """a captured hipGraph bakes in the packed / BN-folded operands of the weights it was captured with.  After
+    load_state_dict() with other weights (tensor versions change, the weight epoch does not) `graph=True` must capture anew --
+    not replay the old weights, not read operands an eager forward in between has freed."""
+    A = pkg.aerial_image_segmentation_api
+    torch.manual_seed(5)
+    model = pkg.archs.UNet_R_SS_v2(3, 3, False).to(dev).eval()
+    torch.manual_seed(6)
+    other = pkg.archs.UNet_R_SS_v2(3, 3, False).to(dev).eval()
+    g = torch.Generator().manual_seed(8)
+    patches = torch.randn(3, 3, 64, 64, generator=g).numpy()
+    a_graph = A.infer_patches(model, patches, batch_size=1, graph=True).numpy()
+    a_eager = A.infer_patches(model, patches, batch_size=1, graph=False).numpy()
+    assert np.abs(a_graph - a_eager).max() < 1e-6
+    model.load_state_dict(other.state_dict())
+    b_eager_first = A.infer_patches(model, patches, batch_size=1, graph=False).numpy()   # eager in between: refills the caches
+    b_graph = A.infer_patches(model, patches, batch_size=1, graph=True).numpy()
+    b_ref = A.infer_patches(other, patches, batch_size=1, graph=False).numpy()
+    assert np.abs(b_eager_first - b_ref).max() < 1e-6
+    assert np.abs(b_graph - b_ref).max() < 1e-6, 'graph replay after load_state_dict returns the old weights\' output'
+    assert np.abs(b_graph - a_graph).max() > 1e-3                                         # the two models do differ

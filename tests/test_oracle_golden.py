@@ -110,3 +110,29 @@ def test_oracle_stage1_matches_reference():
     assert np.allclose(_digests(model.parameters())[:, 1], g['s0_params'][:, 1], rtol=1e-6, atol=1e-6)
     r = O.stage1_step(model, opt, inp, tgt)
     assert np.abs(np.array([r['loss'], r['iou'], r['dice']]) - g['s1_scalars']).max() < 1e-3
+
+
+def test_oracle_data_parallel_step_matches_reference():
+    """"sync-BN-at-W == single-process batch W*b".  The fixture drives the REFERENCE's SynchronizedBatchNorm2d
+    (parallel branch + its own _compute_mean_std) over the concatenated batch of 2 ranks x 2 tiles; the oracle's restatement
+    of that arithmetic must reproduce it."""
+    g = np.load(os.path.join(GOLDEN, 'step_dp_w2_n4_64.npz'))
+    G, D, _, _ = O.make_models()
+    G = O.convert_sync_batchnorm(G); D = O.convert_sync_batchnorm(D)
+    og = torch.optim.Adam(G.parameters(), lr=2e-5); od = torch.optim.Adam(D.parameters(), lr=2e-5)
+    assert [k for k, _ in G.named_parameters()] == [str(k) for k in g['param_names_G']]
+    assert sum(isinstance(m, O.SyncBatchNorm2dCPU) for m in list(G.modules()) + list(D.modules())) == int(g['n_sync_bn'])
+    inp, tgt = O.synthetic_batch(4, 64, 64)
+    assert np.array_equal(inp.numpy(), g['input'])
+    r = O.gan_step(G, D, og, od, inp, tgt)
+    assert np.abs(r['out'].numpy() - g['s0_logits']).max() < 2e-6
+    got = np.array([r[k] for k in ('loss', 'closs', 'adv_g', 'adv_d', 'iou', 'dice')])
+    assert np.abs(got - g['s0_scalars']).max() < 2e-6
+    assert np.allclose(_digests(G.parameters())[:, 1], g['s0_g_step_G'][:, 1], rtol=1e-6, atol=1e-7)
+    assert np.allclose(_digests(D.parameters())[:, 1], g['s0_d_step_D'][:, 1], rtol=1e-6, atol=1e-7)
+    bufs = np.stack([[b.double().sum().item(), b.double().abs().sum().item(), (b.double() ** 2).sum().sqrt().item()] for b in G.buffers()])
+    assert np.allclose(bufs[:, 1], g['s0_bufs_G'][:, 1], rtol=1e-6, atol=1e-7)
+    # and it is NOT the unsynchronised formula: the same step with stock batch norm gives other logits
+    G2, D2, og2, od2 = O.make_models()
+    r2 = O.gan_step(G2, D2, og2, od2, inp, tgt)
+    assert np.abs(r2['out'].numpy() - g['s0_logits']).max() > 1e-5

@@ -29,7 +29,29 @@ def read(directory, counter):
     return acc
 
 
+def write_meta(path):
+    """Sidecar <summary>.meta.json: sha1 of the kernel sources the counters were taken on (bench.py compares it with the
+    sources it runs: `roofline.traffic_stale`) and, when a git checkout is at hand, the commit."""
+    import hashlib
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    d = os.path.join(root, 'ssunet-gan_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h'))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, 'rb').read())
+    meta = {'csrc_sha1': h.hexdigest()[:12], 'git_commit': None}
+    try:
+        meta['git_commit'] = subprocess.check_output(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        pass
+    json.dump(meta, open(path, 'w'))
+
+
 def main():
+    if len(sys.argv) > 3:                 # python tools/pmc_traffic.py fetch_dir write_dir summary.csv  -> also writes summary.meta.json
+        sys.stdout = open(sys.argv[3], 'w')
+        write_meta(sys.argv[3][:-4] + '.meta.json')
     fetch = read(sys.argv[1], 'FETCH_SIZE')
     write = read(sys.argv[2], 'WRITE_SIZE')
     out = csv.writer(sys.stdout)

@@ -17,7 +17,7 @@ S.train_seg_gan.gan_step(*args); torch.cuda.synchronize()
 S.ops.PROFILE = []; S.ops.PROFILE_SHAPES = True
 S.train_seg_gan.gan_step(*args); torch.cuda.synchronize()
 agg = {}
-for label, fl, e0, e1 in S.ops.PROFILE:
+for label, fl, e0, e1, _tag in S.ops.PROFILE:
     a = agg.setdefault(label, [0, 0, 0]); a[0] += fl; a[1] += e0.elapsed_time(e1); a[2] += 1
 tot = sum(a[1] for a in agg.values())
 print('total mfma ms %.1f' % tot)
