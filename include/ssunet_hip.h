@@ -77,7 +77,20 @@ typedef struct {
   double* bnpart;           /* optional batch-norm statistics of the OUTPUT (acc + bias, before res / act): one row [2][Cout]
                              * (sum, sum of squares; fp64) per M-tile, ssg_conv2d_bnpart_rows(d) rows; NULL = off */
   float* ws; int64_t ws_bytes;  /* optional split-K workspace (ssg_conv2d_workspace_bytes(d) bytes, 16-byte aligned); NULL = never split */
+  const void* w_split;      /* optional: the same weights split into three bf16 terms by ssg_pack_weights_split_bf16x3 for the column
+                             * tile ssg_conv2d_split_bn(d) reports; non-NULL selects the split-operand kernel (below).  NULL = fp32 MFMA */
 } ssg_conv_desc;
+
+/* fp32 convolution on the bf16 matrix pipe (3x3, unit stride; archs.py:210,212 and their input gradients, models_seg_gan.py:37-39
+ * stride-1 blocks): every fp32 operand is x = x1 + x2 + x3 with bf16 terms (24 significand bits, exact residuals) and the six
+ * products of order >= 2^-16 go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- one fp32 ulp per product is left
+ * out, results agree with the fp32-MFMA kernel to fp32 accumulation accuracy (tests/test_split_gpu.py), at 16/6 of its
+ * matrix rate.  ssg_conv2d_split_bn: 0 when the launch for `d` has no split-operand kernel, else the column tile (64 / 128)
+ * its weights must be split for: `w_split` = ssg_pack_weights_split_bf16x3(d->w rows [R][Kp] in kmode 0, R, Kp, BN) --
+ * ssg_pack_weights_split_bytes bytes, layout [ceil(R/BN)][Kp/16][BN][128 B]. */
+int ssg_conv2d_split_bn(const ssg_conv_desc* d);
+int64_t ssg_pack_weights_split_bytes(int R, int Kp, int BN);
+int ssg_pack_weights_split_bf16x3(const float* w_packed, int R, int Kp, int BN, void* out, void* stream);
 
 /* Launches whose pixel-tile count leaves most of the chip idle (the 16x16 / 32x32 levels of archs.py:583-589, the
  * Cout <= 64 input gradients of SPADE's gamma|beta conv normalization.py:94-96, batch-1 inference api.py:322) split the

@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ('act', C.c_int), ('slope', C.c_float),
         ('bnpart', C.c_void_p),
         ('ws', C.c_void_p), ('ws_bytes', C.c_int64),
+        ('w_split', C.c_void_p),
     ]
 
 
@@ -64,6 +65,9 @@ SIGNATURES = {
     'ssg_conv2d_kernel_id': [C.POINTER(ConvDesc)],
     'ssg_conv2d_bnpart_rows': [C.POINTER(ConvDesc)],
     'ssg_conv2d_workspace_bytes': [C.POINTER(ConvDesc)],
+    'ssg_conv2d_split_bn': [C.POINTER(ConvDesc)],
+    'ssg_pack_weights_split_bytes': [_I, _I, _I],
+    'ssg_pack_weights_split_bf16x3': [_P, _I, _I, _I, _P, _P],
     'ssg_bn_stats_from_partials_workspace_bytes': [_I, _I],
     'ssg_bn_stats_from_partials_f32': [_P, _I, _I, _P, _D, _P, _P],
     'ssg_conv2d_wgrad_kernel_id': [C.POINTER(WgradDesc)],
@@ -146,6 +150,7 @@ SIGNATURES['ssg_convert_bf16_to_f32'] = [_P, _I, _L, _I, _P, _I, _P]
 _RESTYPES = {
     'ssg_conv2d_wgrad_workspace_bytes': C.c_int64,
     'ssg_conv2d_workspace_bytes': C.c_int64,
+    'ssg_pack_weights_split_bytes': C.c_int64,
     'ssg_bn_workspace_bytes': C.c_int64,
     'ssg_seg_loss_workspace_bytes': C.c_int64,
     'ssg_dwconv2d_wgrad_workspace_bytes': C.c_int64,
@@ -155,10 +160,10 @@ _RESTYPES = {
     'ssg_gemm_wgrad_bf16_workspace_bytes': C.c_int64,
     'ssg_bn_stats_from_partials_workspace_bytes': C.c_int64,
 }
-_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
+_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_split_bn', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
                                 'ssg_spade_conv_modulate_ok'}
 
-ABI_VERSION = 3          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
+ABI_VERSION = 4          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
 
 _lib = None
 

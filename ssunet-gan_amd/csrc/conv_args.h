@@ -32,6 +32,11 @@ int ssg_conv_halo_variant(const ConvArgs& a, int variant);   // 0 = <128,128>, 1
 void ssg_conv_halo_tile(int halo_variant, int* th, int* tw, int* bn);
 int ssg_conv_halo_ksplit(const ConvArgs& a, int variant);    // split-K slabs the launch would use given a workspace (1 = none)
 
+// conv_igemm_halo_x3.hip: the same tiles with operands split into three bf16 terms on the bf16 matrix pipe (a.w = split-packed weights)
+bool ssg_conv_halo_x3_ok(const ConvArgs& a, int variant);
+int ssg_conv_halo_x3_bn(const ConvArgs& a, int variant);      // column tile (64 / 128) the weights must be split-packed for
+int ssg_conv_igemm_halo_x3_launch(const ConvArgs& a, int variant, hipStream_t st);
+
 // Batch-norm statistics in the conv epilogue (halo and DMA kernels): every lane adds up its output column over the rows it
 // holds (<= 32 values) as fp32 deviations from a pivot, converted to fp64 sums of the values once per column (see the
 // kernels: fp32 sums of the raw values lose var = E[x^2] - mean^2 when |mean| >> std); the fp64 partials are folded over the

@@ -223,6 +223,7 @@ int pick_variant(const ssg_conv_desc* d) {
 // register-staged kernel (A/B switch for measurements).
 ConvArgs to_args(const ssg_conv_desc* d);
 bool uses_halo(const ConvArgs& a);
+int split_bn(const ssg_conv_desc* d);
 
 bool uses_dma(const ssg_conv_desc* d) {
   static const int use_dma = [] { const char* e = getenv("SSG_IGEMM_DMA"); return e ? atoi(e) : 1; }();
@@ -293,6 +294,16 @@ ConvArgs to_args(const ssg_conv_desc* d) {
   return a;
 }
 
+// column tile of the split-operand kernel for `d`, or 0: 3x3 unit-stride launches on the halo path that would not split K
+int split_bn(const ssg_conv_desc* d) {
+  if (!uses_dma(d) || d->Cout <= 32) return 0;
+  const ConvArgs a = to_args(d);
+  if (!uses_halo(a) || !ssg_conv_halo_x3_ok(a, pick_variant(d))) return 0;
+  if (d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) && ssg_conv_halo_ksplit(a, pick_variant(d)) > 1) return 0;   // small grids keep split-K
+  return ssg_conv_halo_x3_bn(a, pick_variant(d));
+}
+
+
 }  // namespace
 
 // rows of the batch-norm partial buffer the launch for `d` writes (one per M-tile), or 0 when the kernel `d` maps to has no
@@ -302,7 +313,8 @@ extern "C" int ssg_conv2d_bnpart_rows(const ssg_conv_desc* d) {
   if (ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d) || !uses_dma(d)) return 0;
   const ConvArgs a = to_args(d);
   int th, tw;
-  if (uses_halo(a)) {
+  if (d->w_split && split_bn(d) > 0) { th = 4; tw = 32; }       // split-operand kernel: always 4 x 32-pixel tiles (also where fp32 takes <256,64>)
+  else if (uses_halo(a)) {
     if (d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) && ssg_conv_halo_ksplit(a, pick_variant(d)) > 1) return 0;   // split-K launch: no statistics epilogue
     int bn; ssg_conv_halo_tile(ssg_conv_halo_variant(a, pick_variant(d)), &th, &tw, &bn);
   }
@@ -322,6 +334,11 @@ static int64_t splitk_bytes(const ssg_conv_desc* d, int* ksplit) {
   return (int64_t)k * d->N * d->GH * d->GW * ((d->Cout + 3) & ~3) * (int64_t)sizeof(float);
 }
 
+extern "C" int ssg_conv2d_split_bn(const ssg_conv_desc* d) {
+  if (!d || validate(d) != SSG_OK || ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d) || ssg_conv1x1_k64_ok(d)) return 0;
+  return split_bn(d);
+}
+
 extern "C" int64_t ssg_conv2d_workspace_bytes(const ssg_conv_desc* d) {
   if (!d || validate(d) != SSG_OK || ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d)) return 0;
   int k;
@@ -339,6 +356,11 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
   }
   SSG_REQUIRE(!d->bnpart || uses_dma(d), SSG_EINVAL, "conv: bnpart given but this shape has no statistics epilogue (ssg_conv2d_bnpart_rows == 0)");
   if (uses_dma(d)) {
+    if (d->w_split && split_bn(d) > 0) {                 // operands split into bf16 terms on the bf16 matrix pipe
+      SSG_REQUIRE(ssg_aligned16(d->w_split), SSG_EALIGN, "conv: w_split alignment");
+      a.w = (const float*)d->w_split; a.ws = nullptr; a.ksplit = 1;
+      return ssg_conv_igemm_halo_x3_launch(a, pick_variant(d), st);
+    }
     if (uses_halo(a)) return ssg_conv_igemm_halo_launch(a, pick_variant(d), st);
     return ssg_conv_igemm_dma_launch(a, pick_variant(d), st);
   }

@@ -1,0 +1,294 @@
+// 3x3 stride-1 convolution (forward and input gradient) with fp32 operands SPLIT into three bf16 terms and multiplied on the
+// bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate), fp32 accumulation.  Same contract, LDS halo image and
+// epilogue as conv_igemm_halo.hip; selected when the descriptor carries split-packed weights (ssg_conv_desc.w_split).
+//
+// Arithmetic.  An fp32 value is x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): three 8-bit
+// significands cover the 24 bits of x (the subtractions are exact).  A product of two bf16 values is exact in fp32, so
+//   x*y = x1*y1 + (x1*y2 + x2*y1) + (x1*y3 + x2*y2 + x3*y1) + [x2*y3 + x3*y2 + x3*y3]
+// and the bracket, the only part left out, is below 2^-23 |x*y| with the sign of rounding residuals: one fp32 ulp per
+// product, the class of error an fp32 FMA chain has per step.  Six bf16 MFMAs replace one fp32 MFMA step of the same K at
+// 16/6 = 2.7x its rate.  (This is what cuBLAS calls BF16x9 emulation of FP32, with the three terms of order 2^-24 dropped.)
+//   * weights are split ONCE per pack (ssg_pack_weights_split_bf16x3): per Cout tile and K-step a dense [BN rows][128 B]
+//     block = 3 planes x 16 channels x bf16 (+ 32 B pad), so a step's weights are 16 (BN = 128) contiguous 1-KiB DMA pieces;
+//     the 16-B slot (plane, k-half) of row r sits at position slot ^ ((r >> 1) & 7): the row-per-lane ds_read_b128 of a
+//     column fragment then hits 16 distinct 16-B bank groups in every 16-lane service group (checked by enumeration).
+//   * activations stay fp32 in HBM and in the LDS halo (same DMA, same image as conv_igemm_halo.hip) and are split in
+//     registers as they leave LDS: 8 channels per lane and M fragment -> 3 x bf16x8, ~45 VALU per fragment and step, which
+//     hide under the 24 MFMAs (768 cycles) of the step.
+//   * per step and wave: 4 + 6 ds_read_b128, 24 MFMAs.  LDS: 26 KB halo + 3 x 16 KB weight stages = 74 KB -> 2 workgroups per CU.
+#include "common.h"
+#include "lds_dma.h"
+#include "conv_args.h"
+#include "conv_halo_epilogue.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int XROW = 128;                 // bytes per weight row per K-step: 3 planes x 16 bf16 = 96 B, padded to 128
+
+// x = p1 + p2 + p3 (bf16 each, round-to-nearest-even conversions, exact residuals)
+__device__ __forceinline__ void split3(const f32x4& u, const f32x4& v, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = e < 4 ? u[e] : v[e - 4];
+    const __bf16 h = (__bf16)x;
+    const float r = x - (float)h;
+    const __bf16 m = (__bf16)r;
+    const float r2 = r - (float)m;
+    p1[e] = h; p2[e] = m; p3[e] = (__bf16)r2;
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3_kernel(const ConvArgs a) {
+  constexpr int TWL = 5, TW = 32, TH = BM / TW;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int HW = TW + 2, HR = (TH + 2) * HW;
+  constexpr int AP = (HR + 15) / 16;                     // 1-KiB pieces per halo tile
+  constexpr int APW = (AP + 3) / 4;                      // pieces per wave (dummy-padded), one per step
+  constexpr int B_PC = BN * XROW / 1024 / 4;             // weight pieces per wave per step
+  constexpr int ABUF = AP * 256;                         // floats per halo buffer
+  constexpr int BSTG = BN * XROW;                        // bytes per weight stage
+  static_assert(APW <= 7, "A pieces must be issued before the last two steps of a chunk");
+
+  extern __shared__ __attribute__((aligned(1024))) float lds[];     // 2 * ABUF floats + 3 * BSTG bytes
+  unsigned char* const ldsB = (unsigned char*)(lds + 2 * ABUF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  int bid = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int per = (int)gridDim.x >> 3;
+    if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int nyt = a.ntiles_n;
+  const int nt = bid % nyt; bid /= nyt;
+  const int n0 = nt * BN;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int n = bid / a.tiles_y;
+
+  // ---- DMA sources through buffer descriptors (`buffer_load_dwordx4 ... offen lds`): the per-piece part of an address is a
+  // SCALAR offset and a lane whose halo pixel lies outside the image carries a byte offset beyond the range, which the
+  // hardware answers with zeros -- no pointer arithmetic, select or zero page on the vector unit (this kernel is bound by
+  // vector-instruction issue: 24 MFMAs leave room for ~5 VALU instructions each, the operand split takes most of it)
+  const int lr = lane >> 2, lp = lane & 3;
+  const unsigned a_q = 16u * (unsigned)(lp ^ ((lr >> 2) & 3));       // byte offset of this lane's channel quad (rows of a piece are 16-aligned)
+  const unsigned OOB = 0xffffffffu;                      // beyond any range (ssg_conv_halo_x3_ok admits tensors below 4 GB only)
+  unsigned a_pix[APW];                                   // pixel index of this lane's halo row of piece k, or OOB
+#pragma unroll
+  for (int k = 0; k < APW; ++k) {
+    const int g = wave + 4 * k;
+    const int r = g * 16 + lr;
+    const int hy = r / HW, hx = r - hy * HW;
+    const int iy = ty * TH + hy - 1, ix = tx * TW + hx - 1;
+    const bool ok = g < AP && r < HR && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    a_pix[k] = ok ? (unsigned)((n * a.H + iy) * a.W + ix) : OOB;
+  }
+  const int nchunks = (a.C1 + a.C2) >> 4;
+  const int nsteps = nchunks * 9;
+  const unsigned npix = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W;
+  const auto in1_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1), 0, (int)(npix * (unsigned)a.ld1 * 4u), 0x00020000);
+  const auto in2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in2), 0, (int)(npix * (unsigned)a.ld2 * 4u), 0x00020000);
+  // weights: [Cout tile][step][BN rows][128 B]; this wave's pieces of a step are B_PC consecutive KiB, lane-linear
+  const auto w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)((unsigned)nyt * (unsigned)nsteps * (unsigned)BSTG), 0x00020000);
+  const unsigned w_lane = (unsigned)lane * 16u;
+  const unsigned w_tile = (unsigned)nt * (unsigned)nsteps * (unsigned)BSTG + (unsigned)(wave * B_PC) * 1024u;
+
+  auto issue_a = [&](int chunk, int k) {
+    const int g = wave + 4 * k;
+    if (g >= AP) { return; }
+    ssg_lds_void* dst = (ssg_lds_void*)(lds + (chunk & 1) * ABUF + g * 256);
+    const int c0 = chunk * 16;
+    const bool live = chunk < nchunks;                   // past the last chunk: a dummy piece (all lanes out of range) keeps vmcnt uniform
+    if (c0 < a.C1) {
+      const unsigned vo = (live && a_pix[k] != OOB) ? a_pix[k] * (unsigned)a.ld1 * 4u + a_q : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in1_rs, dst, 16, vo, c0 * 4, 0, 0);
+    } else {
+      const unsigned vo = (live && a_pix[k] != OOB) ? a_pix[k] * (unsigned)a.ld2 * 4u + a_q : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in2_rs, dst, 16, vo, (c0 - a.C1) * 4, 0, 0);
+    }
+  };
+  auto issue_b = [&](int s) {
+    unsigned char* st = ldsB + (s % 3) * BSTG + (wave * B_PC) * 1024;
+    // past the last step the pieces are dummies that keep vmcnt uniform: they re-read step 0 (the scalar offset is not range checked)
+    const unsigned so = w_tile + (s < nsteps ? (unsigned)s * (unsigned)BSTG : 0u);
+#pragma unroll
+    for (int j = 0; j < B_PC; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (ssg_lds_void*)(st + j * 1024), 16, w_lane, so + j * 1024, 0, 0);
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int half = lane >> 5, l31 = lane & 31;
+  int rb[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int p = wm * WTM + i * 32 + l31;
+    rb[i] = ((p >> TWL) + 1) * HW + (p & (TW - 1)) + 1;
+  }
+  // weight fragment j: row (wn*WTN + j*32 + l31) of the stage, slot (2*plane + half) at position slot ^ ((row >> 1) & 7)
+  int boff[NI], bf[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = wn * WTN + j * 32 + l31;
+    boff[j] = row * XROW; bf[j] = (row >> 1) & 7;
+  }
+
+  // ---- prologue
+#pragma unroll
+  for (int k = 0; k < APW; ++k) issue_a(0, k);
+  issue_b(0);
+  issue_b(1);
+  const bool has_last = wave + 4 * (APW - 1) < AP;
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const float* Abuf = lds + (chunk & 1) * ABUF;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int s = chunk * 9 + t;
+      const int tp = (t + 8) % 9;
+      if (tp < APW - 1) wait_vmcnt<B_PC + 1>();
+      else if (tp == APW - 1) { if (has_last) wait_vmcnt<B_PC + 1>(); else wait_vmcnt<B_PC>(); }
+      else wait_vmcnt<B_PC>();
+      wait_lds_reads();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t < APW) issue_a(chunk + 1, t);
+      issue_b(s + 2);
+
+      const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
+      const int toff = ((tb & 7) - 2) * HW + ((tb >> 3) - 2);
+      const unsigned char* Bst = ldsB + (t % 3) * BSTG;                  // s % 3 == t % 3 (9 steps per chunk)
+      bf16x8 a1[MI], a2[MI], a3[MI], b1[NI], b2[NI], b3[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = rb[i] + toff;
+        const int sw = (r >> 2) & 3;
+        const f32x4 u = *(const f32x4*)(Abuf + r * 16 + 4 * ((2 * half) ^ sw));
+        const f32x4 v = *(const f32x4*)(Abuf + r * 16 + 4 * ((2 * half + 1) ^ sw));
+        split3(u, v, a1[i], a2[i], a3[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const unsigned char* row = Bst + boff[j];
+        b1[j] = *(const bf16x8*)(row + 16 * ((0 + half) ^ bf[j]));
+        b2[j] = *(const bf16x8*)(row + 16 * ((2 + half) ^ bf[j]));
+        b3[j] = *(const bf16x8*)(row + 16 * ((4 + half) ^ bf[j]));
+      }
+      // small terms first; consecutive MFMAs go to different accumulators
+#define SSG_X3_TERM(A, B)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+  _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[i][j], 0, 0, 0);
+      SSG_X3_TERM(a3, b1) SSG_X3_TERM(a2, b2) SSG_X3_TERM(a1, b3)
+      SSG_X3_TERM(a2, b1) SSG_X3_TERM(a1, b2)
+      SSG_X3_TERM(a1, b1)
+#undef SSG_X3_TERM
+    }
+  }
+  wait_vmcnt<0>();
+  wait_lds_reads();
+  ssg_halo_epilogue<BM, BN, WAVES_M, WAVES_N, TWL, false>(a, acc, lds, n, ty, tx, n0, 0, wm, wn, half, l31);
+}
+
+// fp32 packed [R][Kp] (kmode 0: k = step*16 + c) -> split tiles [ceil(R/BN)][nsteps][BN][128 B]; one thread per (row, step, k-half)
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, int R, int Kp, int BN, unsigned char* __restrict__ out) {
+  const int nsteps = Kp >> 4;
+  const long long total = (long long)((R + BN - 1) / BN) * BN * nsteps * 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int h = (int)(i & 1);
+    long long t = i >> 1;
+    const int s = (int)(t % nsteps); t /= nsteps;
+    const int row = (int)t;                              // global row (Cout index), padded to the tile
+    const int tile = row / BN, rl = row - tile * BN;
+    bf16x8 p1, p2, p3;
+    if (row < R) {
+      const float* src = w + (size_t)row * Kp + s * 16 + 8 * h;
+      split3(*(const f32x4*)src, *(const f32x4*)(src + 4), p1, p2, p3);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { p1[e] = (__bf16)0.f; p2[e] = (__bf16)0.f; p3[e] = (__bf16)0.f; }
+    }
+    unsigned char* dst = out + ((size_t)tile * nsteps + s) * BN * XROW + (size_t)rl * XROW;
+    const int f = (rl >> 1) & 7;
+    *(bf16x8*)(dst + 16 * ((0 + h) ^ f)) = p1;
+    *(bf16x8*)(dst + 16 * ((2 + h) ^ f)) = p2;
+    *(bf16x8*)(dst + 16 * ((4 + h) ^ f)) = p3;
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  constexpr int TW = 32, TH = BM / TW;
+  constexpr int AP = ((TH + 2) * (TW + 2) + 15) / 16;
+  a.tiles_x = (a.GW + TW - 1) / TW;
+  a.tiles_y = (a.GH + TH - 1) / TH;
+  static const int swz = [] { const char* e = getenv("SSG_XCD_SWIZZLE"); return e ? atoi(e) : 1; }();
+  a.xcd_swizzle = swz;
+  a.ntiles_n = (a.Cout + BN - 1) / BN;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
+  constexpr int lds_bytes = 2 * AP * 1024 + 3 * BN * XROW;
+  static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU");
+  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_halo_x3_kernel<BM, BN, WAVES_M, WAVES_N>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (attr != hipSuccess) { ssg_set_error("conv halo x3: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
+  hipLaunchKernelGGL((conv_igemm_halo_x3_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+}  // namespace
+
+// Column-tile width the split path uses for a launch (= the BN the weights must be split-packed for): 128 where the fp32 path
+// takes <128,128>, 64 otherwise.
+int ssg_conv_halo_x3_bn(const ConvArgs& a, int variant) {
+  const int hv = ssg_conv_halo_variant(a, variant);
+  return hv == 0 ? 128 : 64;
+}
+
+// eligible: the 9 taps of a 3x3 window at unit stride on 32-wide tiles, no split-K, Cout a multiple of the column tile
+bool ssg_conv_halo_x3_ok(const ConvArgs& a, int variant) {
+  if (!ssg_conv_halo_ok(a)) return false;
+  const int hv = ssg_conv_halo_variant(a, variant);
+  if (hv >= 3) return false;                                   // 8x16-pixel tiles (images <= 16 wide)
+  const int bn = hv == 0 ? 128 : 64;
+  const unsigned long long bytes = (unsigned long long)a.N * a.H * a.W * (unsigned long long)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4ull;
+  if (bytes > 0xfffffff0ull) return false;                    // 32-bit byte offsets of the buffer descriptors
+  return a.Cout % bn == 0;
+}
+
+int ssg_conv_igemm_halo_x3_launch(const ConvArgs& a, int variant, hipStream_t st) {
+  // wave layout: 4 x 1 (each wave one 32-pixel tile row x all BN columns) splits each activation fragment once per
+  // workgroup instead of twice (2 x 2); SSG_X3_LAYOUT=22 selects the 2 x 2 layout (A/B)
+  static const int layout = [] { const char* e = getenv("SSG_X3_LAYOUT"); return e ? atoi(e) : 41; }();
+  if (ssg_conv_halo_x3_bn(a, variant) == 128) return layout == 22 ? launch<128, 128, 2, 2>(a, st) : launch<128, 128, 4, 1>(a, st);
+  return layout == 22 ? launch<128, 64, 2, 2>(a, st) : launch<128, 64, 4, 1>(a, st);
+}
+
+extern "C" int64_t ssg_pack_weights_split_bytes(int R, int Kp, int BN) {
+  if (R <= 0 || Kp <= 0 || Kp % 16 || (BN != 64 && BN != 128)) return 0;
+  return (int64_t)((R + BN - 1) / BN) * (Kp / 16) * BN * XROW;
+}
+
+extern "C" int ssg_pack_weights_split_bf16x3(const float* w_packed, int R, int Kp, int BN, void* out, void* stream) {
+  SSG_REQUIRE(w_packed && out && R > 0 && Kp > 0 && Kp % 16 == 0 && (BN == 64 || BN == 128), SSG_EINVAL, "pack_split: bad args");
+  SSG_REQUIRE(ssg_aligned16(w_packed) && ssg_aligned16(out), SSG_EALIGN, "pack_split: 16-B alignment");
+  const long long total = (long long)((R + BN - 1) / BN) * BN * (Kp >> 4) * 2;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_packed, R, Kp, BN, (unsigned char*)out);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}

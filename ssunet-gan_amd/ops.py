@@ -285,15 +285,22 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     _fill_taps(d, taps)
     d.act = act; d.slope = slope
     d.bnpart = None
+    d.ws = None; d.ws_bytes = 0
+    d.w_split = None
+    split = None
+    if MFMA_SPLIT and kmode == 0:      # decided first: the split-operand kernel has its own tile geometry (bnpart rows)
+        bn = call('ssg_conv2d_split_bn', C.byref(d))
+        if bn:
+            split = _split_pack(wpk, row0, cout, kp, bn)
+            d.w_split = split.data_ptr()
     part = None
     if want_bn and BN_EPILOGUE:
         rows = call('ssg_conv2d_bnpart_rows', C.byref(d))
         if rows > 0:
             part = torch.empty((rows, 2, cout), dtype=torch.float64, device=out.device)
             d.bnpart = part.data_ptr()
-    d.ws = None; d.ws_bytes = 0
     ws = None
-    if part is None:                   # split-K (small pixel grids with a long reduction): the kernel needs a workspace
+    if part is None and split is None:  # split-K (small pixel grids with a long reduction): the kernel needs a workspace
         need = call('ssg_conv2d_workspace_bytes', C.byref(d))
         if need > 0:
             ws = _ws(need, out.device)
@@ -302,6 +309,8 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     label = None
     if PROFILE is not None:
         label = _CONV_LABELS.get(call('ssg_conv2d_kernel_id', C.byref(d)), '?') + ('+splitk' if ws is not None else '')
+        if split is not None:
+            label = label.replace('conv_igemm_halo_kernel', 'conv_igemm_halo_x3_kernel').replace('<256,64>', '<128,64>')
         if PROFILE_SHAPES:
             label += ' n%d %dx%d cin%d cout%d taps%d s%d/%d' % (n, gh, gw, cred, cout, len(taps), in_s, out_s)
     with _Timed(label, 2.0 * n * gh * gw * cout * cred * len(taps), tag):
@@ -312,6 +321,29 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
 # SSG_BN_EPILOGUE=0: batch-norm statistics from their own pass over the conv output instead of the conv epilogue (A/B switch)
 import os as _os
 BN_EPILOGUE = _os.environ.get('SSG_BN_EPILOGUE', '1') != '0'
+# SSG_MFMA_SPLIT=1: the dense 3x3 unit-stride convs and input gradients multiply on the bf16 matrix pipe with every fp32
+# operand split into three bf16 terms (csrc/conv_igemm_halo_x3.hip: fp32-class accuracy at 16/6 of the fp32 MFMA rate)
+MFMA_SPLIT = _os.environ.get('SSG_MFMA_SPLIT', '0') == '1'
+
+
+def _split_pack(wpk, row0, rows, kp, bn):
+    """bf16x3 split of rows [row0, row0 + rows) of a packed fp32 weight matrix for column tile `bn` (cached on the packed
+    tensor, which itself lives in the parameter's pack cache: both go stale together)."""
+    cache = wpk.__dict__.get('_ssg_split')
+    if cache is None:
+        cache = {}
+        try:
+            wpk._ssg_split = cache
+        except Exception:
+            pass
+    key = (row0, rows, bn)
+    hit = cache.get(key)
+    if hit is None:
+        nbytes = call('ssg_pack_weights_split_bytes', rows, kp, bn)
+        hit = torch.zeros(nbytes // 2, dtype=torch.int16, device=wpk.device)
+        call('ssg_pack_weights_split_bf16x3', wpk.data_ptr() + row0 * kp * 4, rows, kp, bn, ptr(hit), stream_ptr())
+        cache[key] = hit
+    return hit
 
 
 def _out_size(h, k, s, p):

@@ -1,0 +1,90 @@
+"""fp32 convolution on the bf16 matrix pipe (csrc/conv_igemm_halo_x3.hip, SSG_MFMA_SPLIT=1): every fp32 operand is split
+into three bf16 terms and the six leading products are accumulated in fp32.  The claim to hold: fp32-class accuracy --
+the split kernel must be as close to an fp64 reference as the fp32-MFMA kernel is (same order of magnitude of max and
+rms error), on forward and input gradient, incl. two-pointer inputs, residual epilogue and batch-norm partial rows."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ops, split, fn):
+    old = ops.MFMA_SPLIT
+    ops.MFMA_SPLIT = split
+    try:
+        return fn()
+    finally:
+        ops.MFMA_SPLIT = old
+
+
+@pytest.mark.parametrize('c1,c2,co,hw,nb', [(128, 0, 128, 128, 6), (64, 0, 64, 128, 4), (64, 128, 64, 128, 4), (128, 256, 128, 128, 6), (256, 0, 384, 64, 8)])
+def test_split_conv_matches_fp64_like_fp32_mfma(pkg, dev, c1, c2, co, hw, nb):
+    ops = pkg.ops
+    torch.manual_seed(21)
+    torch.set_num_threads(16)
+    xc = torch.randn(nb, c1 + c2, hw, hw) * 1.5 + 0.3
+    wc = torch.randn(co, c1 + c2, 3, 3) / (3 * (c1 + c2) ** 0.5)
+    rc = torch.randn(nb, co, hw, hw)
+    ref = F.conv2d(xc.double(), wc.double(), None, 1, 1) + rc.double()
+    x1 = ops.to_nhwc(xc[:, :c1].to(dev)); x2 = ops.to_nhwc(xc[:, c1:].to(dev)) if c2 else None
+    w = wc.to(dev); res = ops.to_nhwc(rc.to(dev))
+
+    def fwd():
+        return ops._conv_fwd_impl(x1, x2, w, None, 1, 1, 0, 0.0, res=res)
+    y32 = _run(ops, False, fwd).cpu().double()
+    ops.PROFILE = []
+    try:
+        y3 = _run(ops, True, fwd).cpu().double()
+        labels = [p[0] for p in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert labels and 'halo_x3' in labels[0], 'the split kernel did not run: %s' % labels
+    e32 = (y32 - ref).abs(); e3 = (y3 - ref).abs()
+    assert e3.max().item() <= 2.0 * e32.max().item() + 1e-6, (e3.max().item(), e32.max().item())
+    assert e3.pow(2).mean().sqrt().item() <= 2.0 * e32.pow(2).mean().sqrt().item() + 1e-8
+
+    # input gradient (same kernel, transposed pack) and batch-norm partial rows
+    dyc = torch.randn(nb, co, hw, hw)
+    dy = ops.to_nhwc(dyc.to(dev))
+    gref = torch.nn.grad.conv2d_input((nb, c1 + c2, hw, hw), wc.double(), dyc.double(), 1, 1)[:, :c1]
+
+    def dgrad():
+        return ops._conv_dgrad_impl(dy, w, 1, 1, hw, hw, 0, c1)
+    g32 = _run(ops, False, dgrad).cpu().double(); g3 = _run(ops, True, dgrad).cpu().double()
+    assert (g3 - gref).abs().max().item() <= 2.0 * (g32 - gref).abs().max().item() + 1e-6
+
+    def stats():
+        return ops._conv_fwd_impl(x1, x2, w, None, 1, 1, 0, 0.0, want_bn=True)
+    yb, pb = _run(ops, True, stats)
+    assert pb is not None and pb.numel() > 0
+    # the partial rows are the column sums of what the kernel wrote (fp32 deviations from a pivot, widened to fp64)
+    yd = yb.double()
+    s1 = yd.sum((0, 2, 3)); s2 = (yd * yd).sum((0, 2, 3))
+    tot = pb.sum(0)
+    assert torch.allclose(tot[0], s1, rtol=1e-7, atol=1e-6 * yd.abs().sum((0, 2, 3)).max().item())
+    assert torch.allclose(tot[1], s2, rtol=1e-6)
+
+
+def test_split_step_meets_the_step_tolerances(pkg, dev):
+    """The whole G+D step with the split kernels on: the golden 2 x 64^2 step at the tolerances of tests/test_step_gpu.py."""
+    import os
+    import numpy as np
+    import torch.nn as nn
+    from conftest import GOLDEN
+    ops = pkg.ops
+    gold = np.load(os.path.join(GOLDEN, 'step_n2_64.npz'))
+    torch.manual_seed(41)
+    G = pkg.models_seg_gan.Generator(dict(arch='UNet_R_SS_v2', num_classes=3, input_channels=3, deep_supervision=False)).to(dev).train()
+    D = pkg.models_seg_gan.Discriminator(3, kernel_size=3, n_channels=64, n_blocks=8, fc_size=1024).to(dev).train()
+    og = torch.optim.Adam(G.parameters(), lr=2e-5); od = torch.optim.Adam(D.parameters(), lr=2e-5)
+    g = torch.Generator().manual_seed(7)
+    inp = torch.randn(2, 3, 64, 64, generator=g).to(dev); tgt = (torch.rand(2, 3, 64, 64, generator=g) > 0.5).float().to(dev)
+    tap = {}
+    G.register_forward_hook(lambda m, i, o: tap.__setitem__('logits', o.detach().clone()))
+    out = _run(ops, True, lambda: pkg.train_seg_gan.gan_step(inp, tgt, G, D, pkg.losses.BCEDiceLoss(), nn.BCEWithLogitsLoss(), nn.MSELoss(), og, od, 3))
+    e = np.abs(tap['logits'].cpu().numpy() - gold['s0_logits'])
+    assert e.max() < 2e-4, 'logits err %.3e' % e.max()
+    got = np.array([out[0].item(), out[3].item(), out[4].item(), out[5].item(), out[1].item(), out[2].item()])
+    tol = np.array([2e-5, 5e-5, 1e-4, 2e-4, 1e-4, 1e-4])
+    assert (np.abs(got - gold['s0_scalars']) < tol).all(), (got, gold['s0_scalars'])
