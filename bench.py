@@ -37,6 +37,8 @@ import torch.nn as nn
 D_PASSES = 8 if os.environ.get('SSG_ELIDE_DEAD_D_GRADS', '0') == '1' else 9
 FLOP_PER_IMG_512 = 2 * (3 * 208.625 + D_PASSES * 24.631) * 1e9
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6      # dense bf16: 1024 SIMDs x 1024 FLOP/clk x 2.4 GHz (the guide's "~2.5 PF dense")
+SPLIT_TERMS = 6                     # bf16 MFMAs a split-operand kernel executes per algorithmic fp32 MFMA step (conv_igemm_halo_x3.hip)
 
 
 def _norm_symbol(name):
@@ -237,6 +239,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='tiles per GPU')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32-reference', action='store_true', help='skip the extra steps with every conv on the fp32 MFMA')
     ap.add_argument('--launch-check', action='store_true', help='rendezvous only, no GPU step (CPU rehearsal of the N-rank launch)')
     args = ap.parse_args()
 
@@ -315,6 +318,32 @@ def main():
     prof_hbm, S.ops.PROFILE_HBM = S.ops.PROFILE_HBM, None
     prof_comm, S.ops.PROFILE_COMM = S.ops.PROFILE_COMM, None
     note('timed %d steps: %.1f ms/step' % (args.steps, dt / args.steps * 1e3))
+    # the same step with every conv on the fp32 MFMA (SSG_MFMA_SPLIT=0), measured in THIS run: 1 warm-up + a few timed steps
+    ref32 = None
+    if S.ops.MFMA_SPLIT and not args.no_fp32_reference:
+        S.ops.MFMA_SPLIT = False
+        try:
+            step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            k32 = max(1, min(args.steps, 4))
+            t1 = time.perf_counter()
+            for _ in range(k32):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            d32 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([d32], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d32 = float(t.item())
+            ref32 = {'ms_per_step': round(d32 / k32 * 1e3, 2), 'value': round(args.batch * world * k32 / d32, 3), 'steps': k32,
+                     'step_frac_of_conv_roofline': round(args.batch * k32 / d32 * FLOP_PER_IMG_512 * (args.size / 512.0) ** 2 / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        finally:
+            S.ops.MFMA_SPLIT = True
+        note('fp32-MFMA reference: %.1f ms/step' % ref32['ms_per_step'])
     devices = [torch.cuda.current_device()]
     buckets = None
     if world == 1 and sync_g is not None:                  # SSG_DIST_FORCE=1: one rank, every collective through the backend
@@ -356,20 +385,36 @@ def main():
                 note('WARNING: no PMC traffic row for the dominant kernel %s in %s' % (label, src))
             meta = pmc_traffic_meta(src)
             now = csrc_sha1()
+            def kernel_entry(k, v):
+                e = {'tflops': round(v[0] / v[1] / 1e12, 2), 'time_frac_of_step': round(v[1] / dt, 4), 'launches': v[2]}
+                if '_x3_' in k:         # fp32 operands split into three bf16 terms: 6 bf16 MFMAs per algorithmic fp32 MFMA step
+                    e['pipe'] = 'bf16 (3-term split, fp32 accumulate)'
+                    e['executed_mfma_tflops'] = round(SPLIT_TERMS * v[0] / v[1] / 1e12, 1)
+                    e['executed_frac_of_bf16_peak'] = round(SPLIT_TERMS * v[0] / v[1] / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
+                return e
+            # `achieved` = ALGORITHMIC fp32 conv FLOPs / HIP-event time of the dominant kernel, `peak` = the fp32 MFMA peak (the
+            # dtype of the path).  A split-operand kernel multiplies on the bf16 pipe, so its fraction of the fp32 peak may
+            # exceed 1; `executed` then gives what the matrix pipe really ran against ITS peak.
             roof = {'bound': 'mfma', 'kernel': label, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                     'traffic': traffic, 'traffic_source': src, 'traffic_git_commit': meta.get('git_commit'),
                     'traffic_csrc_sha1': meta.get('csrc_sha1'), 'csrc_sha1': now,
                     'traffic_stale': (meta.get('csrc_sha1') != now) if meta.get('csrc_sha1') else None,
                     'launches': cnt, 'avg_launch_ms': round(tt / cnt * 1e3, 4),
-                    'all_mfma_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'time_frac_of_step': round(v[1] / dt, 4),
-                                             'launches': v[2]} for k, v in sorted(agg.items())},
+                    'all_mfma_kernels': {k: kernel_entry(k, v) for k, v in sorted(agg.items())},
                     'mfma_time_frac_of_step': round(conv_t / dt, 4),
                     'step_frac_of_conv_roofline': round(value * FLOP_PER_IMG_512 * (args.size / 512.0) ** 2 / 1e12 / PEAK_FP32_MFMA_TFLOPS / world, 4)}
+        if roof and '_x3_' in roof['kernel']:
+            roof['executed'] = {'pipe': 'bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 operands split into 3 bf16 terms, 6 of the 9 products, fp32 accumulate',
+                                'achieved': round(SPLIT_TERMS * roof['achieved'], 1), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': round(SPLIT_TERMS * roof['achieved'] / PEAK_BF16_MFMA_TFLOPS, 4)}
         line = {
             'metric': 'train images/sec (512^2 tiles)', 'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'matrix_pipe': ('fp32 tensors and fp32 accumulation everywhere; the dense 3x3 unit-stride convs and input gradients multiply on the bf16 pipe with each '
+                            'fp32 operand split into 3 bf16 terms (error vs fp64 = that of the fp32-MFMA kernel: tests/test_split_gpu.py; SSG_MFMA_SPLIT=0 '
+                            'runs them on v_mfma_f32_32x32x2_f32: `fp32_mfma_reference`)') if S.ops.MFMA_SPLIT else 'v_mfma_f32_32x32x2_f32 (fp32 MFMA) for every conv',
             'config': {'workload': 'UNet_R_SS_v2 generator + SRGAN-style discriminator, one G+D step (train_seg_gan.py:182-233), '
                                    '%d x 3x%dx%d tiles per GPU, fp32, Adam lr 2e-5' % (args.batch, args.size, args.size),
                        'global_batch': args.batch * world, 'tile': args.size,
@@ -390,6 +435,8 @@ def main():
             line['hbm_stages'] = {k: {'gbytes_per_step': round(v[0] / args.steps / 1e9, 3), 'ms_per_step': round(v[1] / args.steps * 1e3, 3),
                                       'launches_per_step': v[2] // args.steps, 'tbps': round(v[0] / v[1] / 1e12, 3),
                                       'frac_of_8tbps': round(v[0] / v[1] / 8e12, 4)} for k, v in sorted(hbm.items())}
+        if ref32 is not None:
+            line['fp32_mfma_reference'] = ref32
         if prof_comm:
             # the sync-BN statistics all-reduces sit on the compute stream between the two stages of every batch norm: their
             # event time is stream time the step cannot overlap (measured, not estimated)

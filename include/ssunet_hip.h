@@ -87,7 +87,7 @@ typedef struct {
  * out, results agree with the fp32-MFMA kernel to fp32 accumulation accuracy (tests/test_split_gpu.py), at 16/6 of its
  * matrix rate.  ssg_conv2d_split_bn: 0 when the launch for `d` has no split-operand kernel, else the column tile (64 / 128)
  * its weights must be split for: `w_split` = ssg_pack_weights_split_bf16x3(d->w rows [R][Kp] in kmode 0, R, Kp, BN) --
- * ssg_pack_weights_split_bytes bytes, layout [ceil(R/BN)][Kp/16][BN][128 B]. */
+ * ssg_pack_weights_split_bytes bytes, layout [ceil(R/BN)][Kp/16][BN][96 B]. */
 int ssg_conv2d_split_bn(const ssg_conv_desc* d);
 int64_t ssg_pack_weights_split_bytes(int R, int Kp, int BN);
 int ssg_pack_weights_split_bf16x3(const float* w_packed, int R, int Kp, int BN, void* out, void* stream);

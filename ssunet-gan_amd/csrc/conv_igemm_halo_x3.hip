@@ -8,14 +8,14 @@
 // and the bracket, the only part left out, is below 2^-23 |x*y| with the sign of rounding residuals: one fp32 ulp per
 // product, the class of error an fp32 FMA chain has per step.  Six bf16 MFMAs replace one fp32 MFMA step of the same K at
 // 16/6 = 2.7x its rate.  (This is what cuBLAS calls BF16x9 emulation of FP32, with the three terms of order 2^-24 dropped.)
-//   * weights are split ONCE per pack (ssg_pack_weights_split_bf16x3): per Cout tile and K-step a dense [BN rows][128 B]
-//     block = 3 planes x 16 channels x bf16 (+ 32 B pad), so a step's weights are 16 (BN = 128) contiguous 1-KiB DMA pieces;
-//     the 16-B slot (plane, k-half) of row r sits at position slot ^ ((r >> 1) & 7): the row-per-lane ds_read_b128 of a
-//     column fragment then hits 16 distinct 16-B bank groups in every 16-lane service group (checked by enumeration).
+//   * weights are split ONCE per pack (ssg_pack_weights_split_bf16x3): per Cout tile and K-step a dense [BN rows][96 B]
+//     block = 3 planes x 16 channels x bf16, so a step's weights are 12 (BN = 128) contiguous 1-KiB DMA pieces; the two
+//     k-halves of a plane swap places in every other group of 8 rows (bank-conflict-free fragment reads, see XROW).
 //   * activations stay fp32 in HBM and in the LDS halo (same DMA, same image as conv_igemm_halo.hip) and are split in
 //     registers as they leave LDS: 8 channels per lane and M fragment -> 3 x bf16x8, ~45 VALU per fragment and step, which
 //     hide under the 24 MFMAs (768 cycles) of the step.
-//   * per step and wave: 4 + 6 ds_read_b128, 24 MFMAs.  LDS: 26 KB halo + 3 x 16 KB weight stages = 74 KB -> 2 workgroups per CU.
+//   * wave layout 4 x 1 (a wave = one 32-pixel tile row x all BN columns): 2 + 12 ds_read_b128, 40 VALU of split, 24 MFMAs per
+//     step and wave.  LDS: 26 KB halo + 3 x 12 KB weight stages = 63 KB -> 2 workgroups per CU.
 #include "common.h"
 #include "lds_dma.h"
 #include "conv_args.h"
@@ -25,7 +25,12 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int XROW = 128;                 // bytes per weight row per K-step: 3 planes x 16 bf16 = 96 B, padded to 128
+constexpr int XROW = 96;                  // bytes per weight row per K-step: 3 planes x 16 bf16, dense
+// 16-B slot (plane p, k-half h) of row r sits at position (2p + h) ^ ((r >> 3) & 1): with the 96-B pitch the slot index of a row
+// is 6r mod 16, which repeats every 8 rows -- swapping the two halves of a plane in every other group of 8 rows puts those on
+// the odd slots, and the row-per-lane ds_read_b128 of a column fragment hits 16 distinct slots in every 16-lane service group
+// (enumerated for both groups {0-3,12-15,20-27}, {4-11,16-19,28-31}).  Dense rows matter: the kernel is bound by the LDS-DMA
+// delivery rate (2 workgroups x (12 KB weights + 1.4 KB halo) per step and CU ~ the 6.4 TB/s the chip sustains), not by MFMA.
 
 // x = p1 + p2 + p3 (bf16 each, round-to-nearest-even conversions, exact residuals)
 __device__ __forceinline__ void split3(const f32x4& u, const f32x4& v, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
@@ -48,13 +53,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3_kernel(const ConvAr
   constexpr int HW = TW + 2, HR = (TH + 2) * HW;
   constexpr int AP = (HR + 15) / 16;                     // 1-KiB pieces per halo tile
   constexpr int APW = (AP + 3) / 4;                      // pieces per wave (dummy-padded), one per step
-  constexpr int B_PC = BN * XROW / 1024 / 4;             // weight pieces per wave per step
+  constexpr int BPIECES = BN * XROW / 1024;              // 12 (BN = 128) / 6 (BN = 64) 1-KiB pieces per step
+  constexpr int B_PC = (BPIECES + 3) / 4;                // per wave and step; indices >= BPIECES are dummies (BN = 64: waves 2, 3)
   constexpr int ABUF = AP * 256;                         // floats per halo buffer
   constexpr int BSTG = BN * XROW;                        // bytes per weight stage
   static_assert(APW <= 7, "A pieces must be issued before the last two steps of a chunk");
 
-  extern __shared__ __attribute__((aligned(1024))) float lds[];     // 2 * ABUF floats + 3 * BSTG bytes
+  extern __shared__ __attribute__((aligned(1024))) float lds[];     // 2 * ABUF floats + 3 * BSTG bytes + 1 KiB dummy target
   unsigned char* const ldsB = (unsigned char*)(lds + 2 * ABUF);
+  unsigned char* const ldsDummy = ldsB + 3 * BSTG;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,10 +101,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3_kernel(const ConvAr
   const unsigned npix = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W;
   const auto in1_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1), 0, (int)(npix * (unsigned)a.ld1 * 4u), 0x00020000);
   const auto in2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in2), 0, (int)(npix * (unsigned)a.ld2 * 4u), 0x00020000);
-  // weights: [Cout tile][step][BN rows][128 B]; this wave's pieces of a step are B_PC consecutive KiB, lane-linear
+  // weights: [Cout tile][step][BN rows][96 B]: a step is BPIECES consecutive lane-linear KiB, dealt to the waves round-robin
   const auto w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)((unsigned)nyt * (unsigned)nsteps * (unsigned)BSTG), 0x00020000);
   const unsigned w_lane = (unsigned)lane * 16u;
-  const unsigned w_tile = (unsigned)nt * (unsigned)nsteps * (unsigned)BSTG + (unsigned)(wave * B_PC) * 1024u;
+  const unsigned w_tile = (unsigned)nt * (unsigned)nsteps * (unsigned)BSTG;
 
   auto issue_a = [&](int chunk, int k) {
     const int g = wave + 4 * k;
@@ -114,12 +121,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3_kernel(const ConvAr
     }
   };
   auto issue_b = [&](int s) {
-    unsigned char* st = ldsB + (s % 3) * BSTG + (wave * B_PC) * 1024;
+    unsigned char* st = ldsB + (s % 3) * BSTG;
     // past the last step the pieces are dummies that keep vmcnt uniform: they re-read step 0 (the scalar offset is not range checked)
     const unsigned so = w_tile + (s < nsteps ? (unsigned)s * (unsigned)BSTG : 0u);
 #pragma unroll
-    for (int j = 0; j < B_PC; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (ssg_lds_void*)(st + j * 1024), 16, w_lane, so + j * 1024, 0, 0);
+    for (int j = 0; j < B_PC; ++j) {
+      const int g = wave + 4 * j;                        // piece index: waves interleave
+      if (g < BPIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (ssg_lds_void*)(st + g * 1024), 16, w_lane, so + g * 1024, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (ssg_lds_void*)ldsDummy, 16, OOB, 0, 0, 0);   // every lane out of range
+    }
   };
 
   f32x16 acc[MI][NI];
@@ -137,12 +147,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3_kernel(const ConvAr
     const int p = wm * WTM + i * 32 + l31;
     rb[i] = ((p >> TWL) + 1) * HW + (p & (TW - 1)) + 1;
   }
-  // weight fragment j: row (wn*WTN + j*32 + l31) of the stage, slot (2*plane + half) at position slot ^ ((row >> 1) & 7)
+  // weight fragment j: row (wn*WTN + j*32 + l31) of the stage, slot (2*plane + half) at position slot ^ ((row >> 3) & 1)
   int boff[NI], bf[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int row = wn * WTN + j * 32 + l31;
-    boff[j] = row * XROW; bf[j] = (row >> 1) & 7;
+    boff[j] = row * XROW; bf[j] = (row >> 3) & 1;
   }
 
   // ---- prologue
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3_kernel(const ConvAr
   ssg_halo_epilogue<BM, BN, WAVES_M, WAVES_N, TWL, false>(a, acc, lds, n, ty, tx, n0, 0, wm, wn, half, l31);
 }
 
-// fp32 packed [R][Kp] (kmode 0: k = step*16 + c) -> split tiles [ceil(R/BN)][nsteps][BN][128 B]; one thread per (row, step, k-half)
+// fp32 packed [R][Kp] (kmode 0: k = step*16 + c) -> split tiles [ceil(R/BN)][nsteps][BN][96 B]; one thread per (row, step, k-half)
 __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, int R, int Kp, int BN, unsigned char* __restrict__ out) {
   const int nsteps = Kp >> 4;
   const long long total = (long long)((R + BN - 1) / BN) * BN * nsteps * 2;
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
       for (int e = 0; e < 8; ++e) { p1[e] = (__bf16)0.f; p2[e] = (__bf16)0.f; p3[e] = (__bf16)0.f; }
     }
     unsigned char* dst = out + ((size_t)tile * nsteps + s) * BN * XROW + (size_t)rl * XROW;
-    const int f = (rl >> 1) & 7;
+    const int f = (rl >> 3) & 1;
     *(bf16x8*)(dst + 16 * ((0 + h) ^ f)) = p1;
     *(bf16x8*)(dst + 16 * ((2 + h) ^ f)) = p2;
     *(bf16x8*)(dst + 16 * ((4 + h) ^ f)) = p3;
@@ -239,7 +249,7 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   a.xcd_swizzle = swz;
   a.ntiles_n = (a.Cout + BN - 1) / BN;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
-  constexpr int lds_bytes = 2 * AP * 1024 + 3 * BN * XROW;
+  constexpr int lds_bytes = 2 * AP * 1024 + 3 * BN * XROW + 1024;
   static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU");
   static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_halo_x3_kernel<BM, BN, WAVES_M, WAVES_N>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -321,9 +321,10 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
 # SSG_BN_EPILOGUE=0: batch-norm statistics from their own pass over the conv output instead of the conv epilogue (A/B switch)
 import os as _os
 BN_EPILOGUE = _os.environ.get('SSG_BN_EPILOGUE', '1') != '0'
-# SSG_MFMA_SPLIT=1: the dense 3x3 unit-stride convs and input gradients multiply on the bf16 matrix pipe with every fp32
-# operand split into three bf16 terms (csrc/conv_igemm_halo_x3.hip: fp32-class accuracy at 16/6 of the fp32 MFMA rate)
-MFMA_SPLIT = _os.environ.get('SSG_MFMA_SPLIT', '0') == '1'
+# The dense 3x3 unit-stride convs and their input gradients multiply on the bf16 matrix pipe with every fp32 operand split into
+# three bf16 terms (csrc/conv_igemm_halo_x3.hip: the error against fp64 is that of the fp32-MFMA kernel, tests/test_split_gpu.py;
+# 16/6 of the fp32 MFMA rate).  SSG_MFMA_SPLIT=0 keeps them on v_mfma_f32_32x32x2_f32 (conv_igemm_halo.hip).
+MFMA_SPLIT = _os.environ.get('SSG_MFMA_SPLIT', '1') == '1'
 
 
 def _split_pack(wpk, row0, rows, kp, bn):

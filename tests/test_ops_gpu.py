@@ -96,9 +96,23 @@ KERNEL_CASES = [
 ]
 
 
+def _split_label(name):
+    """Label of the split-operand kernel (csrc/conv_igemm_halo_x3.hip) that replaces an fp32-MFMA halo kernel label when
+    ops.MFMA_SPLIT is on: 32-wide tiles without split-K only; <256,64> launches take the <128,64> split kernel."""
+    if name.startswith('conv_igemm_halo_kernel<') and '+splitk' not in name:
+        return name.replace('conv_igemm_halo_kernel', 'conv_igemm_halo_x3_kernel').replace('<256,64>', '<128,64>')
+    return name
+
+
+@pytest.mark.parametrize('split', [True, False], ids=['split', 'fp32mfma'])
 @pytest.mark.parametrize('case', KERNEL_CASES)
-def test_conv2d_specialised_kernels(pkg, dev, case):
+def test_conv2d_specialised_kernels(pkg, dev, case, split):
     n, cin, cout, h, w, k, p, expect = case
+    if split:
+        if cout % 64 or not any(_split_label(e) != e for e in expect):      # the split kernels take whole 64 / 128-column tiles
+            pytest.skip('no split-operand kernel on this case')
+        expect = tuple(_split_label(e) for e in expect)
+    pkg.ops.MFMA_SPLIT, saved_split = split, pkg.ops.MFMA_SPLIT
     g = torch.Generator().manual_seed(1234 + cin + cout)
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
@@ -121,6 +135,7 @@ def test_conv2d_specialised_kernels(pkg, dev, case):
         labels = [rec[0] for rec in pkg.ops.PROFILE]
     finally:
         pkg.ops.PROFILE = None
+        pkg.ops.MFMA_SPLIT = saved_split
     for name in expect:
         assert name in labels, '%s did not run (ran: %s)' % (name, labels)
     _close(yd, yr, 1e-5, 2e-6 * math.sqrt(cin * k * k), 'fwd')
@@ -229,7 +244,7 @@ def test_conv2d_concat_halo(pkg, dev):
         labels = [rec[0] for rec in pkg.ops.PROFILE]
     finally:
         pkg.ops.PROFILE = None
-    assert any(l.startswith('conv_igemm_halo_kernel<128,64>') for l in labels) and 'wgrad_halo_kernel<32,128>' in labels, labels
+    assert any(l.startswith(('conv_igemm_halo_kernel<128,64>', 'conv_igemm_halo_x3_kernel<128,64>')) for l in labels) and 'wgrad_halo_kernel<32,128>' in labels, labels
     _close(yd, yr, 1e-5, 7e-5, 'concat halo conv')
     for a, b, nm in zip(d, r, ('dx1', 'dx2', 'dw')):
         _close(a.grad, b.grad, 2e-5, 7e-5, nm)
