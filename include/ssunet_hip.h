@@ -144,13 +144,16 @@ typedef struct {
   int KH, KW, Cin_real;
   float* dw_oihw;           /* [Cout][Cin_real][KH][KW] */
   float* ws; int64_t ws_bytes;
+  int flags;                /* bit 0: 3x3 stride-1 weight gradients multiply on the bf16 matrix pipe with both fp32 operands split into
+                             * three bf16 terms (wgrad_halo_x3_kernel: fp32-class accuracy, see ssg_conv_desc.w_split); 0 = fp32 MFMA */
 } ssg_wgrad_desc;
 
 int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d);
 int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream);
 /* 0..2 = wgrad_kernel<128,128>/<128,64>/<128,32>, 30/31 = wgrad_halo_kernel<32,128>/<64,64> (3x3 stride-1
  * window kept in LDS; default for those), 20/21 = wgrad_dma_kernel<128,128>/<128,64> (default
- * for Cout > 32), 15/16 = wgrad4_kernel (4x4x1 MFMA: dout <= 4 channels / in = 4 channels, the default for
+ * for Cout > 32), 40/41 = wgrad_halo_x3_kernel<32,128>/<64,64> (the halo kernels with split operands, flags bit 0),
+ * 15/16 = wgrad4_kernel (4x4x1 MFMA: dout <= 4 channels / in = 4 channels, the default for
  * those shapes), 13/14 = the opt-in VALU variants */
 int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d);
 

@@ -51,6 +51,7 @@ class WgradDesc(C.Structure):
         ('KH', C.c_int), ('KW', C.c_int), ('Cin_real', C.c_int),
         ('dw_oihw', C.c_void_p),
         ('ws', C.c_void_p), ('ws_bytes', C.c_int64),
+        ('flags', C.c_int),
     ]
 
 
@@ -163,7 +164,7 @@ _RESTYPES = {
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_split_bn', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
                                 'ssg_spade_conv_modulate_ok'}
 
-ABI_VERSION = 4          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
+ABI_VERSION = 5          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
 
 _lib = None
 

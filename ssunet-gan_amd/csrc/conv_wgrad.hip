@@ -307,7 +307,7 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   } else {
     dim3 grid((unsigned)p.mt, (unsigned)p.nt, (unsigned)p.splits);
     if (p.halo) {
-      rc = ssg_wgrad_halo_launch(a, p.variant, grid, st);
+      rc = ssg_wgrad_halo_launch(a, p.variant, grid, st, (d->flags & 1) != 0);
       if (rc != SSG_OK) return rc;
     } else if (wgrad_uses_dma(p.variant)) {
       rc = ssg_wgrad_dma_launch(a, p.variant, grid, st);
@@ -369,7 +369,7 @@ extern "C" int ssg_pack_weights_scaled_f32(const float* w_oihw, int O, int I, in
 extern "C" int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d) {
   if (!d) return SSG_EINVAL;
   if (wgrad4_kind(d)) return 10 + wgrad4_kind(d);
-  if (make_plan(d).halo) return 30 + make_plan(d).variant;
+  if (make_plan(d).halo) return ((d->flags & 1) ? 40 : 30) + make_plan(d).variant;
   const int v = make_plan(d).variant;
   return v + (wgrad_uses_dma(v) ? 20 : 0);
 }

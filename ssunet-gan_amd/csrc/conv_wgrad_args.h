@@ -19,4 +19,4 @@ int ssg_wgrad_dma_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t st
 // (variant 0 = 9 taps x 32 channels x 128 output channels per workgroup, 1 = 9 x 64 x 64)
 int ssg_wgrad_halo_cb(int variant);
 bool ssg_wgrad_halo_ok(const ssg_wgrad_desc* d, int variant);
-int ssg_wgrad_halo_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t st);
+int ssg_wgrad_halo_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t st, bool split);   // split: operands as three bf16 terms on the bf16 pipe

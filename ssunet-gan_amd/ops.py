@@ -240,6 +240,7 @@ _CONV_LABELS = {0: 'conv_igemm_kernel<128,128>', 1: 'conv_igemm_kernel<256,64>',
 _WGRAD_LABELS = {0: 'wgrad_kernel<128,128>', 1: 'wgrad_kernel<128,64>', 2: 'wgrad_kernel<128,32>',
                  20: 'wgrad_dma_kernel<128,128>', 21: 'wgrad_dma_kernel<128,64>',
                  30: 'wgrad_halo_kernel<32,128>', 31: 'wgrad_halo_kernel<64,64>',
+                 40: 'wgrad_halo_x3_kernel<32,128>', 41: 'wgrad_halo_x3_kernel<64,64>',
                  15: 'wgrad4_kernel<thin_cout>', 16: 'wgrad4_kernel<thin_cin>', 17: 'wgrad_tiny4_kernel', 18: 'wgrad32_cin_kernel'}
 
 
@@ -432,6 +433,7 @@ def _conv_wgrad_impl(x1, x2, dy, weight_shape, stride, pad):
     dw = torch.empty((o, i, kh, kw), device=dy.device, dtype=torch.float32)
     d.dw_oihw = dw.data_ptr()
     d.ws = None; d.ws_bytes = 0
+    d.flags = 1 if MFMA_SPLIT else 0
     nbytes = call('ssg_conv2d_wgrad_workspace_bytes', C.byref(d))
     ws = _ws(nbytes, dy.device)
     d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 8

@@ -101,6 +101,8 @@ def _split_label(name):
     ops.MFMA_SPLIT is on: 32-wide tiles without split-K only; <256,64> launches take the <128,64> split kernel."""
     if name.startswith('conv_igemm_halo_kernel<') and '+splitk' not in name:
         return name.replace('conv_igemm_halo_kernel', 'conv_igemm_halo_x3_kernel').replace('<256,64>', '<128,64>')
+    if name.startswith('wgrad_halo_kernel<'):
+        return name.replace('wgrad_halo_kernel', 'wgrad_halo_x3_kernel')
     return name
 
 
@@ -109,9 +111,10 @@ def _split_label(name):
 def test_conv2d_specialised_kernels(pkg, dev, case, split):
     n, cin, cout, h, w, k, p, expect = case
     if split:
-        if cout % 64 or not any(_split_label(e) != e for e in expect):      # the split kernels take whole 64 / 128-column tiles
+        if not any(_split_label(e) != e for e in expect):
             pytest.skip('no split-operand kernel on this case')
-        expect = tuple(_split_label(e) for e in expect)
+        # the split conv kernels take whole 64 / 128-column tiles (other Cout stay on the fp32 MFMA); the weight gradient always splits
+        expect = tuple(_split_label(e) if (cout % 64 == 0 or e.startswith('wgrad')) else e for e in expect)
     pkg.ops.MFMA_SPLIT, saved_split = split, pkg.ops.MFMA_SPLIT
     g = torch.Generator().manual_seed(1234 + cin + cout)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -244,7 +247,8 @@ def test_conv2d_concat_halo(pkg, dev):
         labels = [rec[0] for rec in pkg.ops.PROFILE]
     finally:
         pkg.ops.PROFILE = None
-    assert any(l.startswith(('conv_igemm_halo_kernel<128,64>', 'conv_igemm_halo_x3_kernel<128,64>')) for l in labels) and 'wgrad_halo_kernel<32,128>' in labels, labels
+    assert any(l.startswith(('conv_igemm_halo_kernel<128,64>', 'conv_igemm_halo_x3_kernel<128,64>')) for l in labels), labels
+    assert ('wgrad_halo_x3_kernel<32,128>' if pkg.ops.MFMA_SPLIT else 'wgrad_halo_kernel<32,128>') in labels, labels
     _close(yd, yr, 1e-5, 7e-5, 'concat halo conv')
     for a, b, nm in zip(d, r, ('dx1', 'dx2', 'dw')):
         _close(a.grad, b.grad, 2e-5, 7e-5, nm)

@@ -54,6 +54,23 @@ def test_split_conv_matches_fp64_like_fp32_mfma(pkg, dev, c1, c2, co, hw, nb):
     g32 = _run(ops, False, dgrad).cpu().double(); g3 = _run(ops, True, dgrad).cpu().double()
     assert (g3 - gref).abs().max().item() <= 2.0 * (g32 - gref).abs().max().item() + 1e-6
 
+    # weight gradient: both operands are activations, both split on the fly (wgrad_halo_x3_kernel)
+    wref = torch.nn.grad.conv2d_weight(xc.double(), wc.shape, dyc.double(), 1, 1)
+
+    def wgrad():
+        return ops._conv_wgrad_impl(x1, x2, dy, tuple(w.shape), 1, 1)
+    w32 = _run(ops, False, wgrad).cpu().double()
+    ops.PROFILE = []
+    try:
+        w3 = _run(ops, True, wgrad).cpu().double()
+        wl = [p[0] for p in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert wl and 'wgrad_halo_x3' in wl[0], 'the split weight-gradient kernel did not run: %s' % wl
+    ew32 = (w32 - wref).abs(); ew3 = (w3 - wref).abs()
+    assert ew3.max().item() <= 2.0 * ew32.max().item() + 1e-6 * wref.abs().max().item(), (ew3.max().item(), ew32.max().item())
+    assert ew3.pow(2).mean().sqrt().item() <= 2.0 * ew32.pow(2).mean().sqrt().item() + 1e-8
+
     def stats():
         return ops._conv_fwd_impl(x1, x2, w, None, 1, 1, 0, 0.0, want_bn=True)
     yb, pb = _run(ops, True, stats)

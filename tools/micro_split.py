@@ -38,3 +38,23 @@ for (ci, co, hw) in [(128, 128, 256), (256, 256, 128), (64, 64, 512), (384, 384,
             res.append((split, e0.elapsed_time(e1) / 6))
     t32 = min(t for s_, t in res if not s_); t3 = min(t for s_, t in res if s_)
     print('%4d->%-4d@%-3d fp32 %.3f ms %.1f TF | split %.3f ms %.1f TF-equivalent  (x%.2f)' % (ci, co, hw, t32, fl / t32 / 1e9, t3, fl / t3 / 1e9, t32 / t3), flush=True)
+
+print('weight gradient:')
+for (ci, co, hw) in [(128, 128, 256), (256, 256, 128), (64, 64, 512), (384, 384, 64), (64, 128, 256), (192, 64, 512)]:
+    x = ops.to_nhwc(torch.randn(16, ci, hw, hw, device=dev)); dy = ops.to_nhwc(torch.randn(16, co, hw, hw, device=dev))
+    fl = 2 * 9 * ci * co * 16 * hw * hw
+    res = []
+    for rnd in range(3):
+        for split in (False, True):
+            ops.MFMA_SPLIT = split
+            for _ in range(2):
+                dw = ops._conv_wgrad_impl(x, None, dy, (co, ci, 3, 3), 1, 1)
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(6):
+                dw = ops._conv_wgrad_impl(x, None, dy, (co, ci, 3, 3), 1, 1)
+            e1.record(); torch.cuda.synchronize()
+            res.append((split, e0.elapsed_time(e1) / 6))
+    t32 = min(t for s_, t in res if not s_); t3 = min(t for s_, t in res if s_)
+    print('%4d->%-4d@%-3d fp32 %.3f ms %.1f TF | split %.3f ms %.1f TF-equivalent  (x%.2f)' % (ci, co, hw, t32, fl / t32 / 1e9, t3, fl / t3 / 1e9, t32 / t3), flush=True)
