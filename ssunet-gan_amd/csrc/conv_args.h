@@ -36,6 +36,9 @@ int ssg_conv_halo_ksplit(const ConvArgs& a, int variant);    // split-K slabs th
 bool ssg_conv_halo_x3_ok(const ConvArgs& a, int variant);
 int ssg_conv_halo_x3_bn(const ConvArgs& a, int variant);      // column tile (64 / 128) the weights must be split-packed for
 int ssg_conv_igemm_halo_x3_launch(const ConvArgs& a, int variant, hipStream_t st);
+// conv_igemm_dma_x3.hip: the LDS-DMA pipeline (1x1, stride 2, parity classes) with split operands; column tile 128 / 64 or 0 = not eligible
+int ssg_conv_dma_x3_bn(const ConvArgs& a);
+int ssg_conv_igemm_dma_x3_launch(const ConvArgs& a, hipStream_t st);
 
 // Batch-norm statistics in the conv epilogue (halo and DMA kernels): every lane adds up its output column over the rows it
 // holds (<= 32 values) as fp32 deviations from a pivot, converted to fp64 sums of the values once per column (see the

@@ -298,7 +298,8 @@ ConvArgs to_args(const ssg_conv_desc* d) {
 int split_bn(const ssg_conv_desc* d) {
   if (!uses_dma(d) || d->Cout <= 32) return 0;
   const ConvArgs a = to_args(d);
-  if (!uses_halo(a) || !ssg_conv_halo_x3_ok(a, pick_variant(d))) return 0;
+  if (!uses_halo(a)) return ssg_conv_dma_x3_bn(a);            // 1x1, stride 2, parity-class launches: the LDS-DMA pipeline
+  if (!ssg_conv_halo_x3_ok(a, pick_variant(d))) return 0;
   if (d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) && ssg_conv_halo_ksplit(a, pick_variant(d)) > 1) return 0;   // small grids keep split-K
   return ssg_conv_halo_x3_bn(a, pick_variant(d));
 }
@@ -313,7 +314,9 @@ extern "C" int ssg_conv2d_bnpart_rows(const ssg_conv_desc* d) {
   if (ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d) || !uses_dma(d)) return 0;
   const ConvArgs a = to_args(d);
   int th, tw;
-  if (d->w_split && split_bn(d) > 0) { th = 4; tw = 32; }       // split-operand kernel: always 4 x 32-pixel tiles (also where fp32 takes <256,64>)
+  if (d->w_split && split_bn(d) > 0) {                          // split-operand kernels: 4 x 32-pixel halo tiles (also where fp32 takes <256,64>), 8 x 16 DMA tiles
+    if (uses_halo(a)) { th = 4; tw = 32; } else { th = 8; tw = 16; }
+  }
   else if (uses_halo(a)) {
     if (d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) && ssg_conv_halo_ksplit(a, pick_variant(d)) > 1) return 0;   // split-K launch: no statistics epilogue
     int bn; ssg_conv_halo_tile(ssg_conv_halo_variant(a, pick_variant(d)), &th, &tw, &bn);
@@ -359,6 +362,7 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
     if (d->w_split && split_bn(d) > 0) {                 // operands split into bf16 terms on the bf16 matrix pipe
       SSG_REQUIRE(ssg_aligned16(d->w_split), SSG_EALIGN, "conv: w_split alignment");
       a.w = (const float*)d->w_split; a.ws = nullptr; a.ksplit = 1;
+      if (!uses_halo(a)) return ssg_conv_igemm_dma_x3_launch(a, st);
       return ssg_conv_igemm_halo_x3_launch(a, pick_variant(d), st);
     }
     if (uses_halo(a)) return ssg_conv_igemm_halo_launch(a, pick_variant(d), st);

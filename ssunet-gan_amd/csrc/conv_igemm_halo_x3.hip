@@ -10,7 +10,7 @@
 // 16/6 = 2.7x its rate.  (This is what cuBLAS calls BF16x9 emulation of FP32, with the three terms of order 2^-24 dropped.)
 //   * weights are split ONCE per pack (ssg_pack_weights_split_bf16x3): per Cout tile and K-step a dense [BN rows][96 B]
 //     block = 3 planes x 16 channels x bf16, so a step's weights are 12 (BN = 128) contiguous 1-KiB DMA pieces; the two
-//     k-halves of a plane swap places in every other group of 8 rows (bank-conflict-free fragment reads, see XROW).
+//     k-halves of a plane swap places in every other group of 8 rows (bank-conflict-free fragment reads, see mfma_split.h).
 //   * activations stay fp32 in HBM and in the LDS halo (same DMA, same image as conv_igemm_halo.hip) and are split in
 //     registers as they leave LDS: 8 channels per lane and M fragment -> 3 x bf16x8, ~45 VALU per fragment and step, which
 //     hide under the 24 MFMAs (768 cycles) of the step.
@@ -20,30 +20,9 @@
 #include "lds_dma.h"
 #include "conv_args.h"
 #include "conv_halo_epilogue.h"
+#include "mfma_split.h"
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int XROW = 96;                  // bytes per weight row per K-step: 3 planes x 16 bf16, dense
-// 16-B slot (plane p, k-half h) of row r sits at position (2p + h) ^ ((r >> 3) & 1): with the 96-B pitch the slot index of a row
-// is 6r mod 16, which repeats every 8 rows -- swapping the two halves of a plane in every other group of 8 rows puts those on
-// the odd slots, and the row-per-lane ds_read_b128 of a column fragment hits 16 distinct slots in every 16-lane service group
-// (enumerated for both groups {0-3,12-15,20-27}, {4-11,16-19,28-31}).  Dense rows matter: the kernel is bound by the LDS-DMA
-// delivery rate (2 workgroups x (12 KB weights + 1.4 KB halo) per step and CU ~ the 6.4 TB/s the chip sustains), not by MFMA.
-
-// x = p1 + p2 + p3 (bf16 each, round-to-nearest-even conversions, exact residuals)
-__device__ __forceinline__ void split3(const f32x4& u, const f32x4& v, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = e < 4 ? u[e] : v[e - 4];
-    const __bf16 h = (__bf16)x;
-    const float r = x - (float)h;
-    const __bf16 m = (__bf16)r;
-    const float r2 = r - (float)m;
-    p1[e] = h; p2[e] = m; p3[e] = (__bf16)r2;
-  }
-}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3_kernel(const ConvArgs a) {

@@ -311,7 +311,10 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     if PROFILE is not None:
         label = _CONV_LABELS.get(call('ssg_conv2d_kernel_id', C.byref(d)), '?') + ('+splitk' if ws is not None else '')
         if split is not None:
-            label = label.replace('conv_igemm_halo_kernel', 'conv_igemm_halo_x3_kernel').replace('<256,64>', '<128,64>')
+            if 'halo' in label:
+                label = label.replace('conv_igemm_halo_kernel', 'conv_igemm_halo_x3_kernel').replace('<256,64>', '<128,64>')
+            else:
+                label = 'conv_igemm_dma_x3_kernel<%d>' % bn
         if PROFILE_SHAPES:
             label += ' n%d %dx%d cin%d cout%d taps%d s%d/%d' % (n, gh, gw, cred, cout, len(taps), in_s, out_s)
     with _Timed(label, 2.0 * n * gh * gw * cout * cred * len(taps), tag):

@@ -105,3 +105,48 @@ def test_split_step_meets_the_step_tolerances(pkg, dev):
     got = np.array([out[0].item(), out[3].item(), out[4].item(), out[5].item(), out[1].item(), out[2].item()])
     tol = np.array([2e-5, 5e-5, 1e-4, 2e-4, 1e-4, 1e-4])
     assert (np.abs(got - gold['s0_scalars']) < tol).all(), (got, gold['s0_scalars'])
+
+
+@pytest.mark.parametrize('cin,co,hw,k,stride', [(128, 128, 128, 3, 2), (256, 128, 96, 1, 1), (64, 64, 192, 3, 2), (128, 256, 64, 1, 1)])
+def test_split_dma_family_matches_fp64_like_fp32_mfma(pkg, dev, cin, co, hw, k, stride):
+    """The LDS-DMA pipeline with split operands (conv_igemm_dma_x3.hip): stride-2 3x3 convs, 1x1 convs, and -- through the
+    input gradient of the stride-2 conv -- the four parity-class launches (1 / 2 / 2 / 4 taps, strided outputs)."""
+    ops = pkg.ops
+    torch.manual_seed(23)
+    torch.set_num_threads(16)
+    nb = 4
+    xc = torch.randn(nb, cin, hw, hw) * 1.2 - 0.2
+    wc = torch.randn(co, cin, k, k) / (k * cin ** 0.5)
+    pad = k // 2
+    ref = F.conv2d(xc.double(), wc.double(), None, stride, pad)
+    x = ops.to_nhwc(xc.to(dev)); w = wc.to(dev)
+
+    def fwd():
+        return ops._conv_fwd_impl(x, None, w, None, stride, pad, 0, 0.0)
+    y32 = _run(ops, False, fwd).cpu().double()
+    ops.PROFILE = []
+    try:
+        y3 = _run(ops, True, fwd).cpu().double()
+        labels = [p[0] for p in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert labels and 'dma_x3' in labels[0], 'the split LDS-DMA kernel did not run: %s' % labels
+    e32 = (y32 - ref).abs(); e3 = (y3 - ref).abs()
+    assert e3.max().item() <= 2.0 * e32.max().item() + 1e-6, (e3.max().item(), e32.max().item())
+    assert e3.pow(2).mean().sqrt().item() <= 2.0 * e32.pow(2).mean().sqrt().item() + 1e-8
+    oh = ref.shape[2]
+    dyc = torch.randn(nb, co, oh, oh)
+    dy = ops.to_nhwc(dyc.to(dev))
+    gref = torch.nn.grad.conv2d_input((nb, cin, hw, hw), wc.double(), dyc.double(), stride, pad)
+
+    def dgrad():
+        return ops._conv_dgrad_impl(dy, w, stride, pad, hw, hw, 0, cin)
+    g32 = _run(ops, False, dgrad).cpu().double()
+    ops.PROFILE = []
+    try:
+        g3 = _run(ops, True, dgrad).cpu().double()
+        labels = [p[0] for p in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert any('x3' in l for l in labels), labels
+    assert (g3 - gref).abs().max().item() <= 2.0 * (g32 - gref).abs().max().item() + 1e-6
