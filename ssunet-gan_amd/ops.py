@@ -345,7 +345,7 @@ def _split_pack(wpk, row0, rows, kp, bn):
     hit = cache.get(key)
     if hit is None:
         nbytes = call('ssg_pack_weights_split_bytes', rows, kp, bn)
-        hit = torch.zeros(nbytes // 2, dtype=torch.int16, device=wpk.device)
+        hit = torch.empty(nbytes // 2, dtype=torch.int16, device=wpk.device)
         call('ssg_pack_weights_split_bf16x3', wpk.data_ptr() + row0 * kp * 4, rows, kp, bn, ptr(hit), stream_ptr())
         cache[key] = hit
     return hit
