@@ -392,22 +392,29 @@ def main():
                     e['executed_mfma_tflops'] = round(SPLIT_TERMS * v[0] / v[1] / 1e12, 1)
                     e['executed_frac_of_bf16_peak'] = round(SPLIT_TERMS * v[0] / v[1] / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
                 return e
-            # `achieved` = ALGORITHMIC fp32 conv FLOPs / HIP-event time of the dominant kernel, `peak` = the fp32 MFMA peak (the
-            # dtype of the path).  A split-operand kernel multiplies on the bf16 pipe, so its fraction of the fp32 peak may
-            # exceed 1; `executed` then gives what the matrix pipe really ran against ITS peak.
-            roof = {'bound': 'mfma', 'kernel': label, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            # `achieved` = ALGORITHMIC fp32 conv FLOPs / HIP-event time of the dominant kernel.  `peak` = the ceiling of the pipe that
+            # kernel multiplies on, in the same algorithmic unit: the fp32 MFMA peak for a v_mfma_f32_32x32x2_f32 kernel; for a
+            # split-operand kernel the dense bf16 MFMA peak / 6 (six bf16 MFMAs of the same shape stand for one fp32 product:
+            # DESIGN.md 3.9) -- `executed` restates that in executed bf16 FLOP/s, `frac_of_fp32_mfma_peak` against the fp32 pipe.
+            split_dom = '_x3_' in label
+            peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if split_dom else PEAK_FP32_MFMA_TFLOPS
+            roof = {'bound': 'mfma', 'kernel': label, 'achieved': round(ach, 2), 'peak': round(peak, 1),
+                    'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                    'peak_is': ('dense bf16 MFMA peak %.1f / %d products per fp32 multiply (split-operand kernel)' % (PEAK_BF16_MFMA_TFLOPS, SPLIT_TERMS))
+                               if split_dom else 'dense fp32 MFMA peak',
+                    'fp32_mfma_peak': PEAK_FP32_MFMA_TFLOPS, 'frac_of_fp32_mfma_peak': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                     'traffic': traffic, 'traffic_source': src, 'traffic_git_commit': meta.get('git_commit'),
                     'traffic_csrc_sha1': meta.get('csrc_sha1'), 'csrc_sha1': now,
                     'traffic_stale': (meta.get('csrc_sha1') != now) if meta.get('csrc_sha1') else None,
                     'launches': cnt, 'avg_launch_ms': round(tt / cnt * 1e3, 4),
                     'all_mfma_kernels': {k: kernel_entry(k, v) for k, v in sorted(agg.items())},
                     'mfma_time_frac_of_step': round(conv_t / dt, 4),
-                    'step_frac_of_conv_roofline': round(value * FLOP_PER_IMG_512 * (args.size / 512.0) ** 2 / 1e12 / PEAK_FP32_MFMA_TFLOPS / world, 4)}
-        if roof and '_x3_' in roof['kernel']:
-            roof['executed'] = {'pipe': 'bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 operands split into 3 bf16 terms, 6 of the 9 products, fp32 accumulate',
-                                'achieved': round(SPLIT_TERMS * roof['achieved'], 1), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                'frac': round(SPLIT_TERMS * roof['achieved'] / PEAK_BF16_MFMA_TFLOPS, 4)}
+                    'step_frac_of_fp32_mfma_roofline': round(value * FLOP_PER_IMG_512 * (args.size / 512.0) ** 2 / 1e12 / PEAK_FP32_MFMA_TFLOPS / world, 4)}
+            roof['step_frac_of_conv_roofline'] = roof['step_frac_of_fp32_mfma_roofline']       # the name rounds 1-2 reported
+            if split_dom:
+                roof['executed'] = {'pipe': 'bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 operands split into 3 bf16 terms, 6 of the 9 products, fp32 accumulate',
+                                    'achieved': round(SPLIT_TERMS * ach, 1), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': round(SPLIT_TERMS * ach / PEAK_BF16_MFMA_TFLOPS, 4)}
         line = {
             'metric': 'train images/sec (512^2 tiles)', 'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
@@ -429,7 +436,8 @@ def main():
         if enc[2]:
             line['encoder_3x3'] = {'flops_per_step': round(enc[0] / args.steps), 'launches_per_step': enc[2] // args.steps,
                                    'ms_per_step': round(enc[1] / args.steps * 1e3, 3), 'tflops': round(enc[0] / enc[1] / 1e12, 2),
-                                   'frac': round(enc[0] / enc[1] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   'frac': round(enc[0] / enc[1] / 1e12 / (PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if S.ops.MFMA_SPLIT else PEAK_FP32_MFMA_TFLOPS), 4),
+                                   'frac_of_fp32_mfma_peak': round(enc[0] / enc[1] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                    'algorithmic_gmac_per_img': ENCODER_3X3_GMAC_PER_IMG_512 * (args.size / 512.0) ** 2}
         if hbm:
             line['hbm_stages'] = {k: {'gbytes_per_step': round(v[0] / args.steps / 1e9, 3), 'ms_per_step': round(v[1] / args.steps * 1e3, 3),
