@@ -406,6 +406,10 @@ int ssg_spectral_norm_bwd_f32(const float* dWsn, const float* W, int rows, int c
  * Measured ceilings of the device the job runs on: back-to-back fp32 32x32x2 MFMA issue
  * (FLOPs = blocks*4*iters*16*4096; scratch holds blocks*256 floats) and a 16-B/lane HBM copy. */
 int ssg_tool_mfma_peak_f32(float* scratch, int blocks, int iters, void* stream);
+/* the same loop with v_mfma_f32_32x32x16_bf16 (32768 FLOP each): the ceiling of the split-operand kernels on this device */
+int ssg_tool_mfma_peak_bf16(float* scratch, int blocks, int iters, void* stream);
+/* ... on caller operands (`data`: 64 KiB of bf16 values), which toggle the multiplier inputs: the power-limited rate */
+int ssg_tool_mfma_peak_bf16_data(float* scratch, int blocks, int iters, const void* data, void* stream);
 int ssg_tool_copy_f32(const float* src, float* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus

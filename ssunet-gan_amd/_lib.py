@@ -139,6 +139,8 @@ SIGNATURES = {
     'ssg_gemm_wgrad_bf16_workspace_bytes': [_L, _I, _I],
     'ssg_gemm_wgrad_bf16': [_P, _I, _P, _I, _L, _I, _I, _P, _P, _L, _P],
     'ssg_tool_mfma_peak_f32': [_P, _I, _I, _P],
+    'ssg_tool_mfma_peak_bf16': [_P, _I, _I, _P],
+    'ssg_tool_mfma_peak_bf16_data': [_P, _I, _I, _P, _P],
     'ssg_tool_copy_f32': [_P, _P, _L, _P],
 }
 

@@ -26,6 +26,59 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// the same loop on the bf16 pipe: v_mfma_f32_32x32x16_bf16 (32768 FLOP each), what the split-operand kernels multiply on
+__global__ __launch_bounds__(256) void mfma_peak_bf16_kernel(float* out, int iters) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  bf16x8_t a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(1.0f + (threadIdx.x + e) * 0.0078125f); b[e] = (__bf16)(0.5f + (blockIdx.x % 64 + e) * 0.00390625f); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    asm volatile("" : "+v"(a));
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// ... and with operands that toggle: 4 + 4 fragments of caller data (random bf16), cycled.  The register-only loops above run
+// on constants, which cost the matrix pipe little power; this one shows the rate the chip sustains on real operands.
+__global__ __launch_bounds__(256) void mfma_peak_bf16_data_kernel(float* out, int iters, const bf16x8_t* __restrict__ data) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  bf16x8_t a[4], b[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { a[u] = data[(u * 256 + threadIdx.x) & 4095]; b[u] = data[(1024 + u * 256 + threadIdx.x + blockIdx.x) & 4095]; }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[i], acc[i], 0, 0, 0);
+    asm volatile("" : "+v"(a[0]));
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long long nq) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long long)gridDim.x * 256) dst[i] = src[i];
 }
@@ -37,6 +90,22 @@ __global__ __launch_bounds__(256) void copy_kernel(const f32x4* __restrict__ src
 extern "C" int ssg_tool_mfma_peak_f32(float* scratch, int blocks, int iters, void* stream) {
   SSG_REQUIRE(scratch && blocks > 0 && iters > 0, SSG_EINVAL, "mfma_peak: bad args");
   hipLaunchKernelGGL(mfma_peak_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+// Same launch shape on the bf16 pipe.  FLOPs = blocks * 4 * iters * 16 * 32768.
+extern "C" int ssg_tool_mfma_peak_bf16(float* scratch, int blocks, int iters, void* stream) {
+  SSG_REQUIRE(scratch && blocks > 0 && iters > 0, SSG_EINVAL, "mfma_peak_bf16: bad args");
+  hipLaunchKernelGGL(mfma_peak_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+// `data`: 4096 x 16 B of bf16 operands (64 KiB).
+extern "C" int ssg_tool_mfma_peak_bf16_data(float* scratch, int blocks, int iters, const void* data, void* stream) {
+  SSG_REQUIRE(scratch && data && blocks > 0 && iters > 0, SSG_EINVAL, "mfma_peak_bf16_data: bad args");
+  hipLaunchKernelGGL(mfma_peak_bf16_data_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters, (const bf16x8_t*)data);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

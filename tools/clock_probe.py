@@ -6,6 +6,9 @@ Needs the diagnostic build of the library (no stamp executes in the product buil
   cd ssunet-gan_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSSG_CLOCK_PROBE -c conv_igemm_halo.hip -o /tmp/halo_probe.o
   hipcc -shared -fPIC --offload-arch=gfx950 $(ls *.o | grep -v conv_igemm_halo.o) /tmp/halo_probe.o -o ../libssunet_probe.so
   python tools/clock_probe.py
+
+`python tools/clock_probe.py x3` stamps the pre-split bf16x3 kernel instead (conv_igemm_halo_x3.hip built with the same define
+and linked into the same probe library): does the chip hold its clock when the loop runs on the bf16 pipe?
 """
 import ctypes as C
 import os
@@ -23,7 +26,9 @@ from ssunet_gan_amd._lib import ACT_NONE  # noqa: E402
 dev = 'cuda'
 lib = _lib.load()
 probe = torch.zeros(2 * 65536, dtype=torch.int64, device=dev)
-rc = lib.ssg_debug_set_probe_buffer(C.c_void_p(probe.data_ptr()))
+X3 = len(sys.argv) > 1 and sys.argv[1] == 'x3'
+ops.MFMA_SPLIT = X3
+rc = getattr(lib, 'ssg_debug_set_probe_buffer_x3' if X3 else 'ssg_debug_set_probe_buffer')(C.c_void_p(probe.data_ptr()))
 assert rc == 0, rc
 torch.manual_seed(0)
 for (ci, co, hw) in [(128, 128, 256), (256, 256, 128), (64, 64, 512)]:
@@ -42,5 +47,6 @@ for (ci, co, hw) in [(128, 128, 256), (256, 256, 128), (64, 64, 512)]:
     clk = (p[:, 0].double() / p[:, 1].double() * 100e6).median().item() / 1e9
     flops = 2.0 * 16 * hw * hw * ci * co * 9
     print('cin%d cout%d %dx%d: %.1f TFLOP/s (wall, incl. launch), in-kernel clock %.2f GHz over %d workgroups, '
-          'fp32 MFMA peak at that clock %.1f TFLOP/s' % (ci, co, hw, hw, flops / dt / 1e12, clk, p.shape[0], 256 * 4 * 64 * clk / 1e3), flush=True)
+          '%s MFMA peak at that clock %.1f TFLOP/s' % (ci, co, hw, hw, flops / dt / 1e12, clk, p.shape[0], 'bf16' if X3 else 'fp32',
+                                                      256 * 4 * (1024 if X3 else 64) * clk / 1e3), flush=True)
     probe.zero_()
