@@ -310,7 +310,7 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
       rc = ssg_wgrad_halo_launch(a, p.variant, grid, st, (d->flags & 1) != 0);
       if (rc != SSG_OK) return rc;
     } else if (wgrad_uses_dma(p.variant)) {
-      rc = ssg_wgrad_dma_launch(a, p.variant, grid, st);
+      rc = ssg_wgrad_dma_launch(a, p.variant, grid, st, (d->flags & 1) != 0);
       if (rc != SSG_OK) return rc;
     } else
     switch (p.variant) {
@@ -365,11 +365,11 @@ extern "C" int ssg_pack_weights_scaled_f32(const float* w_oihw, int O, int I, in
   return SSG_OK;
 }
 
-// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 30/31 = wgrad_halo<32,128>/<64,64>, 15/16 = wgrad4 (4x4x1 MFMA)
+// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 30/31 = wgrad_halo<32,128>/<64,64>, 40/41 / 50/51 = the split-operand (x3) forms of 30/31 / 20/21, 15/16 = wgrad4 (4x4x1 MFMA)
 extern "C" int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d) {
   if (!d) return SSG_EINVAL;
   if (wgrad4_kind(d)) return 10 + wgrad4_kind(d);
   if (make_plan(d).halo) return ((d->flags & 1) ? 40 : 30) + make_plan(d).variant;
   const int v = make_plan(d).variant;
-  return v + (wgrad_uses_dma(v) ? 20 : 0);
+  return v + (wgrad_uses_dma(v) ? ((d->flags & 1) ? 50 : 20) : 0);
 }

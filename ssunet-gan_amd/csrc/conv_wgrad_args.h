@@ -9,11 +9,12 @@ struct WgArgs {
   int M;                 // ntaps * Cin
   long long Ptot;        // N*GH*GW
   int steps_per_split;   // K-steps (16 pixels each) per z-slice
+  int xcd_swizzle;       // conv_wgrad_dma.hip: sharers of an operand on one XCD (set by the launcher)
 };
 
 
 // conv_wgrad_dma.hip: LDS-DMA pipeline for Cout > 32 (variant 0 = <128,128>, 1 = <128,64>)
-int ssg_wgrad_dma_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t st);
+int ssg_wgrad_dma_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t st, bool split);
 
 // conv_wgrad_halo.hip: 3x3 stride-1 weight gradient with an LDS-resident pixel window
 // (variant 0 = 9 taps x 32 channels x 128 output channels per workgroup, 1 = 9 x 64 x 64)

@@ -6,9 +6,14 @@
 //   * 3 stages, two K-steps (2 x 16 pixels) in flight across the one barrier per step;
 //   * shifted/out-of-image taps and the pixel tail read a zero page instead of being predicated;
 //   * the per-lane pixel coordinate advances incrementally (no divisions in the loop).
+// X3 = true: the same pipeline multiplying on the bf16 pipe with both fp32 operands split into three bf16 terms as they
+// leave LDS (mfma_split.h; arithmetic and error as in conv_igemm_halo_x3.hip).  A K-step of 16 pixels is ONE
+// v_mfma_f32_32x32x16_bf16 per term pair: a lane gathers its row's 8 pixels (8 ds_read_b32, as many as the fp32 form
+// reads), splits them (~45 VALU per fragment) and issues 6 MFMAs per (M, N) fragment pair where the fp32 form issues 8.
 #include "common.h"
 #include "lds_dma.h"
 #include "conv_wgrad_args.h"
+#include "mfma_split.h"
 
 namespace {
 
@@ -18,8 +23,8 @@ __device__ __attribute__((aligned(64))) float ssg_zero_page_w[64];
 constexpr int BKP = 16;
 constexpr int NSTAGE = 3;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool X3>
+__device__ __forceinline__ void wgrad_dma_body(const WgArgs& a) {
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / 32, NI = WTN / 32;
   constexpr int A_PC = BKP * BM / 256 / 4;       // pieces per wave per step (BM=128: 2)
@@ -33,10 +38,26 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int half = lane >> 5, l31 = lane & 31;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // Workgroup -> (row block, column block, K slice).  The row blocks of one (column block, K slice) stream the SAME dy pixels
+  // and the column blocks of one row block the same input pixels; linear workgroup ids go round-robin over the 8 XCDs, each
+  // with its own L2, so the natural x-fastest order puts the sharers on eight different L2s and every one of them fetches the
+  // shared operand from HBM (stride-2 3x3 layers: 9 row blocks -> dy read 9 times; PMC round 2: 3.3-4.6 TB/s).  Remap so that
+  // the row blocks of a group follow one another on ONE XCD (groups dealt to the XCDs in turn); a tail of < 8 groups keeps
+  // the natural order.
+  int bx = blockIdx.x, g = blockIdx.y + gridDim.y * blockIdx.z;
+  if (a.xcd_swizzle) {
+    const int mt = gridDim.x, G = gridDim.y * gridDim.z;
+    const int L = bx + mt * g;
+    if (L < (G >> 3) * 8 * mt) {
+      const int q = L >> 3;
+      bx = q % mt; g = (q / mt) * 8 + (L & 7);
+    }
+  }
+  const int by = g % (int)gridDim.y, bz = g / (int)gridDim.y;
+  const int m0 = bx * BM, n0 = by * BN;
   const int Cin = a.C1 + a.C2;
 
-  const long long step0 = (long long)blockIdx.z * a.steps_per_split;
+  const long long step0 = (long long)bz * a.steps_per_split;
   long long nst = (a.Ptot + BKP - 1) / BKP - step0;
   if (nst > a.steps_per_split) nst = a.steps_per_split;
   const int nsteps = nst > 0 ? (int)nst : 0;
@@ -111,6 +132,34 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
     asm volatile("" ::: "memory");
     if (s + 2 < nsteps) issue(s + 2);
     const float* st = lds + (s % NSTAGE) * STAGE;
+    if constexpr (X3) {
+      // lane (row l31, k-half h) holds pixels 8h .. 8h + 7 of the step
+      const float* Ab = st + 8 * half * BM + wm * WTM + l31;
+      const float* Bb = st + BKP * BM + 8 * half * BN + wn * WTN + l31;
+      bf16x8 a1[MI], a2[MI], a3[MI], b1[NI], b2[NI], b3[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        f32x4 u, v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { u[k] = Ab[k * BM + i * 32]; v[k] = Ab[(4 + k) * BM + i * 32]; }
+        split3(u, v, a1[i], a2[i], a3[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        f32x4 u, v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { u[k] = Bb[k * BN + j * 32]; v[k] = Bb[(4 + k) * BN + j * 32]; }
+        split3(u, v, b1[j], b2[j], b3[j]);
+      }
+#define SSG_X3_TERM(A, B)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+  _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[i][j], 0, 0, 0);
+      SSG_X3_TERM(a3, b1) SSG_X3_TERM(a2, b2) SSG_X3_TERM(a1, b3)
+      SSG_X3_TERM(a2, b1) SSG_X3_TERM(a1, b2)
+      SSG_X3_TERM(a1, b1)
+#undef SSG_X3_TERM
+    } else {
     const float* Ab = st + half * BM + wm * WTM + l31;
     const float* Bb = st + BKP * BM + half * BN + wn * WTN + l31;
 #pragma unroll
@@ -126,9 +175,10 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
+    }
   }
 
-  float* slab = a.ws + (size_t)blockIdx.z * a.M * a.Cout;
+  float* slab = a.ws + (size_t)bz * a.M * a.Cout;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -142,11 +192,25 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) {
     }
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgArgs a) { wgrad_dma_body<BM, BN, WAVES_M, WAVES_N, false>(a); }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_dma_x3_kernel(const WgArgs a) { wgrad_dma_body<BM, BN, 2, 2, true>(a); }
+
 }  // namespace
 
-int ssg_wgrad_dma_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t st) {
-  if (variant == 0) hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, a);
+int ssg_wgrad_dma_launch(const WgArgs& a0, int variant, dim3 grid, hipStream_t st, bool split) {
+  WgArgs a = a0;
+  static const int swz = [] { const char* e = getenv("SSG_XCD_SWIZZLE"); return e ? atoi(e) : 1; }();
+  a.xcd_swizzle = swz;
+  if (split) {
+    if (variant == 0) hipLaunchKernelGGL((wgrad_dma_x3_kernel<128, 128>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_dma_x3_kernel<128, 64>), grid, dim3(256), 0, st, a);
+  } else {
+    if (variant == 0) hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_dma_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, a);
+  }
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -241,6 +241,7 @@ _WGRAD_LABELS = {0: 'wgrad_kernel<128,128>', 1: 'wgrad_kernel<128,64>', 2: 'wgra
                  20: 'wgrad_dma_kernel<128,128>', 21: 'wgrad_dma_kernel<128,64>',
                  30: 'wgrad_halo_kernel<32,128>', 31: 'wgrad_halo_kernel<64,64>',
                  40: 'wgrad_halo_x3_kernel<32,128>', 41: 'wgrad_halo_x3_kernel<64,64>',
+                 50: 'wgrad_dma_x3_kernel<128,128>', 51: 'wgrad_dma_x3_kernel<128,64>',
                  15: 'wgrad4_kernel<thin_cout>', 16: 'wgrad4_kernel<thin_cin>', 17: 'wgrad_tiny4_kernel', 18: 'wgrad32_cin_kernel'}
 
 

@@ -103,6 +103,8 @@ def _split_label(name):
         return name.replace('conv_igemm_halo_kernel', 'conv_igemm_halo_x3_kernel').replace('<256,64>', '<128,64>')
     if name.startswith('wgrad_halo_kernel<'):
         return name.replace('wgrad_halo_kernel', 'wgrad_halo_x3_kernel')
+    if name.startswith('wgrad_dma_kernel<'):
+        return name.replace('wgrad_dma_kernel', 'wgrad_dma_x3_kernel')
     return name
 
 

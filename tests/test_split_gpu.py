@@ -150,3 +150,20 @@ def test_split_dma_family_matches_fp64_like_fp32_mfma(pkg, dev, cin, co, hw, k, 
         ops.PROFILE = None
     assert any('x3' in l for l in labels), labels
     assert (g3 - gref).abs().max().item() <= 2.0 * (g32 - gref).abs().max().item() + 1e-6
+
+    # weight gradient of the same layer: wgrad_dma_x3_kernel (both operands split as they leave LDS)
+    wref = torch.nn.grad.conv2d_weight(xc.double(), wc.shape, dyc.double(), stride, pad)
+
+    def wgrad():
+        return ops._conv_wgrad_impl(x, None, dy, tuple(w.shape), stride, pad)
+    w32 = _run(ops, False, wgrad).cpu().double()
+    ops.PROFILE = []
+    try:
+        w3 = _run(ops, True, wgrad).cpu().double()
+        wl = [p[0] for p in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert wl and 'wgrad_dma_x3' in wl[0], 'the split LDS-DMA weight-gradient kernel did not run: %s' % wl
+    ew32 = (w32 - wref).abs(); ew3 = (w3 - wref).abs()
+    assert ew3.max().item() <= 2.0 * ew32.max().item() + 1e-6 * wref.abs().max().item(), (ew3.max().item(), ew32.max().item())
+    assert ew3.pow(2).mean().sqrt().item() <= 2.0 * ew32.pow(2).mean().sqrt().item() + 1e-8
