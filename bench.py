@@ -118,9 +118,14 @@ def measured_ceilings(S, dev):
     mfma = 768 * 4 * it * 16 * 4096 / ms / 1e9
     ms = timeit(lambda: call('ssg_tool_mfma_peak_bf16', ptr(scratch), 768, 2 * it, stream_ptr()), 3)
     mfma16 = 768 * 4 * 2 * it * 16 * 32768 / ms / 1e9
+    # ... and on random operands: constants cost the multipliers little power, real data pulls the clock down --
+    # long enough (~0.25 s per launch) for the clock to settle
+    data = torch.randn(4096 * 8, device=dev).to(torch.bfloat16)
+    ms = timeit(lambda: call('ssg_tool_mfma_peak_bf16_data', ptr(scratch), 768, 100 * it, ptr(data), stream_ptr()), 2)
+    mfma16r = 768 * 4 * 100 * it * 16 * 32768 / ms / 1e9
     a = torch.empty(1 << 27, device=dev); b = torch.empty(1 << 27, device=dev)
     ms = timeit(lambda: call('ssg_tool_copy_f32', ptr(a), ptr(b), a.numel(), stream_ptr()), 3)
-    return {'mfma_f32_tflops': round(mfma, 1), 'mfma_bf16_tflops': round(mfma16, 1), 'hbm_copy_tbps': round(2 * a.numel() * 4 / ms / 1e9, 2)}
+    return {'mfma_f32_tflops': round(mfma, 1), 'mfma_bf16_tflops': round(mfma16, 1), 'mfma_bf16_random_operand_tflops': round(mfma16r, 1), 'hbm_copy_tbps': round(2 * a.numel() * 4 / ms / 1e9, 2)}
 
 
 def host_cores():
