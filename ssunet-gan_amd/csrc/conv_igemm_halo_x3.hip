@@ -12,8 +12,8 @@
 //     block = 3 planes x 16 channels x bf16, so a step's weights are 12 (BN = 128) contiguous 1-KiB DMA pieces; the two
 //     k-halves of a plane swap places in every other group of 8 rows (bank-conflict-free fragment reads, see mfma_split.h).
 //   * activations stay fp32 in HBM and arrive in the LDS halo by the same DMA as in conv_igemm_halo.hip.  Default form
-//     (conv_igemm_halo_x3p_kernel): each 16-channel halo image is split ONCE into a second LDS image of [pixel][96 B] rows and
-//     the nine taps read ready fragments.  Older form (conv_igemm_halo_x3_kernel, SSG_X3_PRESPLIT=0): fragments are split in
+//     (conv_igemm_halo_x3_kernel): each 16-channel halo image is split ONCE into a second LDS image of [pixel][96 B] rows and
+//     the nine taps read ready fragments.  Older form (conv_igemm_halo_x3r_kernel, SSG_X3_PRESPLIT=0): fragments are split in
 //     registers as they leave LDS, ~45 VALU per fragment and step.  Same results bit for bit (the split is exact either way).
 //   * wave layout 4 x 1 (a wave = one 32-pixel tile row x all BN columns): 3 + 12 ds_read_b128 and 24 MFMAs per step and wave
 //     (BN = 128).  LDS: 13 KB fp32 image + 20 KB split image + 3 x 12 KB weight stages = 70 KB -> 2 workgroups per CU; BN = 64:
@@ -35,7 +35,7 @@ __device__ unsigned long long* ssg_probe_buf_x3 = nullptr;
 #endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3r_kernel(const ConvArgs a) {
   constexpr int TWL = 5, TW = 32, TH = BM / TW;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / 32, NI = WTN / 32;
@@ -208,9 +208,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3_kernel(const ConvAr
 // VALU per step; SQ counters of round 3: 2.7 VALU per MFMA, MFMA busy 61 %).  The fp32 image is single-buffered (the DMA of
 // chunk c + 1 is issued after chunk c has been converted); a chunk boundary costs one conversion pass (2 x 13 KB read, 19 KB
 // written by 256 threads) and one extra barrier per 9 steps.  LDS: 13 KB fp32 image + 20 KB split image + 3 weight stages + 1 KB.
-template <int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_halo_x3p_kernel(const ConvArgs a) {
-  constexpr int TWL = 5, TW = 32, TH = 4, BM = 128;
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_halo_x3_kernel(const ConvArgs a) {
+  static_assert(BM == 128, "4 rows of 32 pixels");
+  constexpr int TWL = 5, TW = 32, TH = 4;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / 32, NI = WTN / 32;
   constexpr int HW = TW + 2, HR = (TH + 2) * HW;
@@ -441,10 +442,10 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
   constexpr int lds_bytes = 2 * AP * 1024 + 3 * BN * XROW + 1024;
   static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU");
-  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_halo_x3_kernel<BM, BN, WAVES_M, WAVES_N>,
+  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_halo_x3r_kernel<BM, BN, WAVES_M, WAVES_N>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (attr != hipSuccess) { ssg_set_error("conv halo x3: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
-  hipLaunchKernelGGL((conv_igemm_halo_x3_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_igemm_halo_x3r_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -462,9 +463,9 @@ int launch_p(const ConvArgs& a0, hipStream_t st) {
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
   constexpr int lds_bytes = AP * 1024 + ((AP * 16 * XROW + 1023) / 1024) * 1024 + 3 * BN * XROW + 1024;
   static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU");
-  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_halo_x3p_kernel<BN, WAVES_M, WAVES_N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  if (attr != hipSuccess) { ssg_set_error("conv halo x3p: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
-  hipLaunchKernelGGL((conv_igemm_halo_x3p_kernel<BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_halo_x3_kernel<128, BN, WAVES_M, WAVES_N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (attr != hipSuccess) { ssg_set_error("conv halo x3: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
+  hipLaunchKernelGGL((conv_igemm_halo_x3_kernel<128, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
