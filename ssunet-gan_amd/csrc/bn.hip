@@ -345,9 +345,13 @@ int run_reduce(const T* x, const T* y, const T* dy, long long P, int C, int ldx,
 
 }  // namespace
 
+// One query serves the fp32 reducers (4 channels per thread) and the bf16 ones (8): the larger of the two geometries, each
+// with its own channel padding -- not "Q = 1 happens to be the larger" (ADVICE r2).
 extern "C" int64_t ssg_bn_workspace_bytes(int64_t P, int C) {
-  const RedGeom g = red_geom(P, C);
-  return (int64_t)g.parts * 2 * 4 * ((C + 3) / 4) * (int64_t)sizeof(double);
+  const RedGeom g1 = red_geom(P, C, 1), g2 = red_geom(P, C, 2);
+  const int64_t b1 = (int64_t)g1.parts * 2 * 4 * ((C + 3) / 4) * (int64_t)sizeof(double);
+  const int64_t b2 = (int64_t)g2.parts * 2 * 8 * ((C + 7) / 8) * (int64_t)sizeof(double);
+  return b1 > b2 ? b1 : b2;
 }
 
 namespace {

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
     const int q = lp ^ ((r >> 2) & 3);
     kq[j] = 8 * q;
     xs[j] = (p0 + r < a.P) ? a.x + (size_t)(p0 + r) * a.ldx + 8 * q : nullptr;
-    ws[j] = a.w + (size_t)(n0 + r) * a.Kp + 8 * q;          // packed rows are padded to the tile: always in range
+    ws[j] = (n0 + r < a.N) ? a.w + (size_t)(n0 + r) * a.Kp + 8 * q : nullptr;   // rows past N read the zero page: no assumption about the pack's row padding
   }
   const unsigned short* zero = ssg_zero_page_bf16;
 
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs a) {
       dma16h(p, st + GB_N * 64 + (wave * 2 + j) * 1024);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma16h(ws[j] + k0, st + (wave * 2 + j) * 1024);
+    for (int j = 0; j < 2; ++j) dma16h(ws[j] ? ws[j] + k0 : zero, st + (wave * 2 + j) * 1024);
   };
 
   f32x16 acc[2][2];
