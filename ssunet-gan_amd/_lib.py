@@ -138,6 +138,9 @@ SIGNATURES = {
     'ssg_gemm_bf16': [_P, _L, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P],
     'ssg_gemm_wgrad_bf16_workspace_bytes': [_L, _I, _I],
     'ssg_gemm_wgrad_bf16': [_P, _I, _P, _I, _L, _I, _I, _P, _P, _L, _P],
+    'ssg_se_gate_ok': [_I, _I, _I],
+    'ssg_se_gate_fwd_f32': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    'ssg_se_gate_bwd_f32': [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     'ssg_tool_mfma_peak_f32': [_P, _I, _I, _P],
     'ssg_tool_mfma_peak_bf16': [_P, _I, _I, _P],
     'ssg_tool_mfma_peak_bf16_data': [_P, _I, _I, _P, _P],
@@ -164,7 +167,7 @@ _RESTYPES = {
     'ssg_bn_stats_from_partials_workspace_bytes': C.c_int64,
 }
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_split_bn', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
-                                'ssg_spade_conv_modulate_ok'}
+                                'ssg_spade_conv_modulate_ok', 'ssg_se_gate_ok'}
 
 ABI_VERSION = 5          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
 

@@ -49,8 +49,10 @@ class MBConvBlock(nn.Module):
         x = ops.batch_norm_act(self._depthwise_conv(x), self._bn1, act=ACT_SWISH)
         if self.has_se:
             sq = ops.global_avgpool(x)
-            sq = self._se_expand(self._swish(self._se_reduce(sq)))
-            x = ops.channel_scale(x, ops.sigmoid(sq))
+            gate = ops.se_gate(sq, self._se_reduce, self._se_expand)          # model.py:84-86 in 2 + 3 kernels (csrc/se_gate.hip)
+            if gate is None:
+                gate = ops.sigmoid(self._se_expand(self._swish(self._se_reduce(sq))))
+            x = ops.channel_scale(x, gate)
         x = self._project_conv(x)
         a = self._block_args
         # model.py:93-94 compares `stride == 1` literally: decoded BlockArgs carry stride as a LIST ([1]), so
@@ -74,8 +76,10 @@ class MBConvBlock(nn.Module):
         x = bf16.batch_norm_act(bf16.dwconv2d(x, dw.weight, dw.stride[0], dw.static_pad), self._bn1, act=ACT_SWISH)
         if self.has_se:
             sq = bf16.global_avgpool(x)
-            sq = self._se_expand(self._swish(self._se_reduce(sq)))
-            x = bf16.channel_scale(x, ops.sigmoid(sq))
+            gate = ops.se_gate(sq, self._se_reduce, self._se_expand)
+            if gate is None:
+                gate = ops.sigmoid(self._se_expand(self._swish(self._se_reduce(sq))))
+            x = bf16.channel_scale(x, gate)
         x = bf16.conv1x1(x, self._project_conv.weight)
         a = self._block_args
         skip = self.id_skip and a.stride == 1 and a.input_filters == a.output_filters

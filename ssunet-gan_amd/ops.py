@@ -1282,6 +1282,59 @@ def global_avgpool(x):
     return _GlobalAvgPool.apply(x)
 
 
+SE_FUSED = _os.environ.get('SSG_SE_FUSED', '1') != '0'
+
+
+class _SEGate(torch.autograd.Function):
+    """sigmoid(_se_expand(swish(_se_reduce(sq)))) on the pooled [N, C, 1, 1] vector (efficientnet_pytorch/model.py:84-86) as
+    2 kernels forward and 3 backward (csrc/se_gate.hip) instead of two 1x1 conv launches with their packs, activations,
+    split-K slabs and reducers."""
+
+    @staticmethod
+    def forward(ctx, sq, w1, b1, w2, b2):
+        sq = to_nhwc(sq)
+        n, c = sq.shape[0], sq.shape[1]
+        s_ = w1.shape[0]
+        dev = sq.device
+        w1c = w1.detach().reshape(s_, c).contiguous(); w2c = w2.detach().reshape(c, s_).contiguous()
+        h_pre = torch.empty((n, s_), dtype=torch.float32, device=dev)
+        gate = new_nhwc(n, c, 1, 1, dev)
+        call('ssg_se_gate_fwd_f32', ptr(sq), _ld(sq), n, c, ptr(w1c), ptr(b1.detach()) if b1 is not None else None, ptr(w2c),
+             ptr(b2.detach()) if b2 is not None else None, s_, ptr(h_pre), ptr(gate), _ld(gate), stream_ptr())
+        ctx.save_for_backward(sq, w1c, w2c, h_pre, gate)
+        ctx.cfg = (n, c, s_, tuple(w1.shape), tuple(w2.shape), b1 is not None, b2 is not None)
+        return gate
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dgate):
+        sq, w1c, w2c, h_pre, gate = ctx.saved_tensors
+        n, c, s_, shp1, shp2, has_b1, has_b2 = ctx.cfg
+        dev = sq.device
+        dgate = to_nhwc(dgate)
+        dsq = new_nhwc(n, c, 1, 1, dev)
+        dw1 = torch.empty((s_, c), dtype=torch.float32, device=dev); dw2 = torch.empty((c, s_), dtype=torch.float32, device=dev)
+        db1 = torch.empty(s_, dtype=torch.float32, device=dev) if has_b1 else None
+        db2 = torch.empty(c, dtype=torch.float32, device=dev) if has_b2 else None
+        tmp = torch.empty(n * c + n * s_, dtype=torch.float32, device=dev)
+        call('ssg_se_gate_bwd_f32', ptr(dgate), _ld(dgate), ptr(gate), _ld(gate), ptr(h_pre), ptr(sq), _ld(sq), n, c, ptr(w1c), ptr(w2c), s_,
+             ptr(dsq), _ld(dsq), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(tmp), stream_ptr())
+        return dsq, dw1.reshape(shp1), db1, dw2.reshape(shp2), db2
+
+
+def se_gate(sq, reduce_conv, expand_conv):
+    """The squeeze-excite gate for pooled `sq` [N, C, 1, 1] through the block's `_se_reduce` / `_se_expand` 1x1 conv modules;
+    None when the shape is outside the fused kernels' range (the caller then runs the convs)."""
+    _lib.require_gpu(sq)
+    w1, w2 = reduce_conv.weight, expand_conv.weight
+    n, c = sq.shape[0], sq.shape[1]
+    if not SE_FUSED or tuple(w1.shape[1:]) != (c, 1, 1) or tuple(w2.shape) != (c, w1.shape[0], 1, 1) or sq.dtype != torch.float32:
+        return None
+    if not call('ssg_se_gate_ok', n, c, w1.shape[0]):
+        return None
+    return _SEGate.apply(sq, w1, reduce_conv.bias, w2, expand_conv.bias)
+
+
 class _ChannelScale(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, s):

@@ -31,3 +31,36 @@ def test_bn_epilogue_statistics_with_large_mean(pkg, dev, k, min_ratio):
         rel = ((st[1].double() - inv) / inv).abs().max().item()
         assert rel < 5e-6, '%s: invstd relative error %.3e at mean/std %.0f' % (name, rel, ratio)
     assert ((st_epi[1] - st_own[1]) / st_own[1]).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize('n,c,s', [(4, 144, 6), (4, 2688, 112), (16, 96, 4), (3, 40, 10), (16, 1152, 48)])
+def test_se_gate_matches_the_two_convs(pkg, dev, n, c, s):
+    """csrc/se_gate.hip: sigmoid(_se_expand(swish(_se_reduce(sq)))) forward and all five gradients against plain torch
+    (efficientnet_pytorch/model.py:84-86; utils.py:37-48 for the swish derivative)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.manual_seed(5 + c)
+    red = nn.Conv2d(c, s, 1); exp = nn.Conv2d(s, c, 1)
+    sq = torch.randn(n, c, 1, 1) * 0.7
+    g = torch.randn(n, c, 1, 1)
+    sqr = sq.double().requires_grad_(True)
+    w1 = red.weight.double().detach().requires_grad_(True); b1 = red.bias.double().detach().requires_grad_(True)
+    w2 = exp.weight.double().detach().requires_grad_(True); b2 = exp.bias.double().detach().requires_grad_(True)
+    h = F.conv2d(sqr, w1, b1)
+    ref = torch.sigmoid(F.conv2d(h * torch.sigmoid(h), w2, b2))
+    ref.backward(g.double())
+    red = red.to(dev); exp = exp.to(dev)
+    sqd = sq.to(dev).requires_grad_(True)
+    out = pkg.ops.se_gate(sqd, red, exp)
+    assert out is not None, 'shape inside the fused range'
+    out.backward(g.to(dev))
+
+    def close(a, b, what):
+        a = a.detach().cpu().double().reshape(b.shape); err = (a - b).abs().max().item(); ref_ = b.abs().max().item()
+        assert err <= 2e-6 * max(ref_, 1.0) + 1e-5 * ref_, '%s: %.3e vs max %.3e' % (what, err, ref_)
+    close(out, ref.detach(), 'gate')
+    close(sqd.grad, sqr.grad, 'dsq')
+    close(red.weight.grad, w1.grad, 'dw1'); close(red.bias.grad, b1.grad, 'db1')
+    close(exp.weight.grad, w2.grad, 'dw2'); close(exp.bias.grad, b2.grad, 'db2')
+    # outside the range the caller keeps the conv path
+    assert pkg.ops.se_gate(torch.randn(17, c, 1, 1, device=dev), red, exp) is None
