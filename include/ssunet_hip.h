@@ -408,12 +408,14 @@ int ssg_spectral_norm_bwd_f32(const float* dWsn, const float* W, int rows, int c
  * them and the sigmoid after them (the pooling and the gating product stay ssg_sample_channel_sum_* / ssg_channel_scale_*):
  *   h_pre[n][s] = b1[s] + sum_c w1[s][c] * sq[n][c]          (w1 = _se_reduce.weight [S][C][1][1], b1 may be NULL)
  *   gate[n][c]  = sigmoid(b2[c] + sum_s w2[c][s] * swish(h_pre[n][s]))   (w2 = _se_expand.weight [C][S][1][1])
- * h_pre ([N][S], dense) is kept for the backward.  Range: N <= 16, S <= 256, N*S <= 4096 (ssg_se_gate_ok; outside it the
+ * h_pre ([N][S], dense) is kept for the backward.  Range: N <= 16, S <= 256, N*S <= 2048 (ssg_se_gate_ok; outside it the
  * caller keeps the conv path).  Backward: from dgate it writes dsq [N][C] (stride lds_), dw1 [S][C], db1 [S] (may be NULL),
- * dw2 [C][S], db2 [C] (may be NULL); tmp = (N*C + N*S) floats of scratch.  All sums run in a fixed order. */
+ * dw2 [C][S], db2 [C] (may be NULL).  tmp = ssg_se_gate_workspace_floats(N, C, S) floats of scratch in either direction
+ * (partial sums per 64-channel chunk; dz in the backward).  All sums run in a fixed order. */
 int ssg_se_gate_ok(int N, int C, int S);
+int64_t ssg_se_gate_workspace_floats(int N, int C, int S);
 int ssg_se_gate_fwd_f32(const float* sq, int ldq, int N, int C, const float* w1, const float* b1, const float* w2, const float* b2,
-                        int S, float* h_pre, float* gate, int ldg, void* stream);
+                        int S, float* h_pre, float* gate, int ldg, float* tmp, void* stream);
 int ssg_se_gate_bwd_f32(const float* dgate, int ldd, const float* gate, int ldg, const float* h_pre, const float* sq, int ldq, int N, int C,
                         const float* w1, const float* w2, int S, float* dsq, int lds_, float* dw1, float* db1, float* dw2, float* db2,
                         float* tmp, void* stream);

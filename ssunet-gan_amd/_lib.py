@@ -139,7 +139,8 @@ SIGNATURES = {
     'ssg_gemm_wgrad_bf16_workspace_bytes': [_L, _I, _I],
     'ssg_gemm_wgrad_bf16': [_P, _I, _P, _I, _L, _I, _I, _P, _P, _L, _P],
     'ssg_se_gate_ok': [_I, _I, _I],
-    'ssg_se_gate_fwd_f32': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    'ssg_se_gate_workspace_floats': [_I, _I, _I],
+    'ssg_se_gate_fwd_f32': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
     'ssg_se_gate_bwd_f32': [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     'ssg_tool_mfma_peak_f32': [_P, _I, _I, _P],
     'ssg_tool_mfma_peak_bf16': [_P, _I, _I, _P],
@@ -158,6 +159,7 @@ _RESTYPES = {
     'ssg_conv2d_workspace_bytes': C.c_int64,
     'ssg_pack_weights_split_bytes': C.c_int64,
     'ssg_bn_workspace_bytes': C.c_int64,
+    'ssg_se_gate_workspace_floats': C.c_int64,
     'ssg_seg_loss_workspace_bytes': C.c_int64,
     'ssg_dwconv2d_wgrad_workspace_bytes': C.c_int64,
     'ssg_spectral_norm_workspace_bytes': C.c_int64,

@@ -3,48 +3,78 @@
 // for the pooled [N][C] vector.  The reference runs it as two 1x1 convs on a 1x1 image plus two activation modules; as conv
 // launches that is 6 kernels forward and 12 backward per block (weight packs, split-K slabs and their reducers for matrices of a
 // few hundred KB), 32 blocks per EfficientNet-B4 step -- launch time, not work.  Here: 2 kernels forward, 3 backward, every sum in
-// a fixed order (deterministic), fp32 throughout.  N <= 16 samples, S <= 256 squeezed channels, N*S <= 4096.
+// a fixed order (deterministic), fp32 throughout.  N <= 16 samples, S <= 256 squeezed channels, N*S <= 2048.
 #include "common.h"
 
 namespace {
 
 constexpr int SE_MAXN = 16;
 
-__device__ __forceinline__ float wave_sum(float v) {
+// The two contractions over the C channels (h = W1 sq, dL/dswish(h) = W2^T dz) are split into 64-channel chunks: one thread per
+// (sample, squeezed channel) pair and chunk sums its 64 products, the consumer adds the <= C/64 partials in a fixed order.  (One
+// wave per squeezed channel streaming all C channels: 22-43 us per launch on a 28-workgroup grid, latency-bound; per-channel
+// threads with a wave butterfly per (n, s): 53-60 us, shuffle-bound.)
+constexpr int SE_CK = 64;
+
+// sum_k part[k][i] in a fixed order, eight loads in flight
+__device__ __forceinline__ float sum_parts(const float* __restrict__ part, int nck, int NS, int i) {
+  float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= nck; k += 8)
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+    for (int u = 0; u < 8; ++u) z[u] += part[(size_t)(k + u) * NS + i];
+  for (; k < nck; ++k) z[0] += part[(size_t)k * NS + i];
+  return ((z[0] + z[1]) + (z[2] + z[3])) + ((z[4] + z[5]) + (z[6] + z[7]));
 }
 
-// h_pre[n][s] = b1[s] + sum_c w1[s][c] * sq[n][c]: one wave per squeezed channel s, lanes over c
-__global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ sq, int ldq, int N, int C, const float* __restrict__ w1,
-                                                        const float* __restrict__ b1, int S, float* __restrict__ h_pre) {
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= S) return;
-  float acc[SE_MAXN];
-#pragma unroll
-  for (int n = 0; n < SE_MAXN; ++n) acc[n] = 0.f;
-  for (int c = lane; c < C; c += 64) {
-    const float wv = w1[(size_t)s * C + c];
-#pragma unroll
-    for (int n = 0; n < SE_MAXN; ++n)
-      if (n < N) acc[n] = fmaf(wv, sq[(size_t)n * ldq + c], acc[n]);
+// part[k][n][s] = sum_{c in chunk k} w1[s][c] * sq[n][c]
+__global__ __launch_bounds__(256) void se_hidden_part_kernel(const float* __restrict__ sq, int ldq, int N, int C, const float* __restrict__ w1,
+                                                             int S, float* __restrict__ part) {
+  const int i = blockIdx.x * 256 + threadIdx.x;          // n * S + s
+  if (i >= N * S) return;
+  const int n = i / S, s_ = i - n * S;
+  const int c0 = blockIdx.y * SE_CK, c1 = c0 + SE_CK < C ? c0 + SE_CK : C;
+  const float* wr = w1 + (size_t)s_ * C;
+  const float* qr = sq + (size_t)n * ldq;
+  float acc = 0.f;
+  if (c1 - c0 == SE_CK) {
+#pragma unroll 16
+    for (int c = 0; c < SE_CK; ++c) acc = fmaf(wr[c0 + c], qr[c0 + c], acc);
+  } else {
+    for (int c = c0; c < c1; ++c) acc = fmaf(wr[c], qr[c], acc);
   }
-  const float bv = b1 ? b1[s] : 0.f;
-#pragma unroll
-  for (int n = 0; n < SE_MAXN; ++n)
-    if (n < N) {
-      const float t = wave_sum(acc[n]);
-      if (lane == 0) h_pre[n * S + s] = t + bv;
-    }
+  part[(size_t)blockIdx.y * N * S + i] = acc;
 }
 
-// gate[n][c] = sigmoid(b2[c] + sum_s w2[c][s] * swish(h_pre[n][s])): one thread per channel c, swish(h) staged in LDS
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ h_pre, int N, int S, const float* __restrict__ w2,
-                                                      const float* __restrict__ b2, int C, float* __restrict__ gate, int ldg) {
+// part[k][n][s] = sum_{c in chunk k} w2[c][s] * dz[n][c]      (threads of consecutive s read consecutive addresses)
+__global__ __launch_bounds__(256) void se_dh_part_kernel(const float* __restrict__ dz, int N, int C, const float* __restrict__ w2, int S,
+                                                         float* __restrict__ part) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * S) return;
+  const int n = i / S, s_ = i - n * S;
+  const int c0 = blockIdx.y * SE_CK, c1 = c0 + SE_CK < C ? c0 + SE_CK : C;
+  const float* zr = dz + (size_t)n * C;
+  float acc = 0.f;
+  if (c1 - c0 == SE_CK) {
+#pragma unroll 16
+    for (int c = 0; c < SE_CK; ++c) acc = fmaf(w2[(size_t)(c0 + c) * S + s_], zr[c0 + c], acc);
+  } else {
+    for (int c = c0; c < c1; ++c) acc = fmaf(w2[(size_t)c * S + s_], zr[c], acc);
+  }
+  part[(size_t)blockIdx.y * N * S + i] = acc;
+}
+
+// h_pre[n][s] = b1[s] + sum_k part[k][n][s] (workgroup 0 stores it for the backward);
+// gate[n][c] = sigmoid(b2[c] + sum_s w2[c][s] * swish(h_pre[n][s]))
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ b1, int N, int S,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2, int C,
+                                                      float* __restrict__ h_pre, float* __restrict__ gate, int ldg) {
   extern __shared__ float hs[];                          // [N][S]
-  for (int i = threadIdx.x; i < N * S; i += 256) { const float z = h_pre[i]; hs[i] = z * ssg_sigmoid_fast(z); }
+  for (int i = threadIdx.x; i < N * S; i += 256) {
+    const float z = (b1 ? b1[i % S] : 0.f) + sum_parts(part, nblk, N * S, i);
+    if (blockIdx.x == 0) h_pre[i] = z;
+    hs[i] = z * ssg_sigmoid_fast(z);
+  }
   __syncthreads();
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
@@ -53,18 +83,32 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
 #pragma unroll
   for (int n = 0; n < SE_MAXN; ++n) acc[n] = bv;
   const float* wr = w2 + (size_t)c * S;
-  for (int s = 0; s < S; ++s) {
-    const float wv = wr[s];
+  if ((S & 3) == 0) {                                    // rows are 16-byte aligned: a quarter of the (per-thread-row) load instructions
+#pragma unroll 2
+    for (int s = 0; s < S; s += 4) {
+      const f32x4 wv = *(const f32x4*)(wr + s);
 #pragma unroll
-    for (int n = 0; n < SE_MAXN; ++n)
-      if (n < N) acc[n] = fmaf(wv, hs[n * S + s], acc[n]);
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int n = 0; n < SE_MAXN; ++n)
+          if (n < N) acc[n] = fmaf(wv[e], hs[n * S + s + e], acc[n]);
+    }
+  } else {
+#pragma unroll 4
+    for (int s = 0; s < S; ++s) {
+      const float wv = wr[s];
+#pragma unroll
+      for (int n = 0; n < SE_MAXN; ++n)
+        if (n < N) acc[n] = fmaf(wv, hs[n * S + s], acc[n]);
+    }
   }
 #pragma unroll
   for (int n = 0; n < SE_MAXN; ++n)
     if (n < N) gate[(size_t)n * ldg + c] = ssg_sigmoid_fast(acc[n]);
 }
 
-// per channel c: dz[n][c] = dgate * g * (1 - g); db2[c] = sum_n dz; dw2[c][s] = sum_n dz[n][c] * swish(h_pre[n][s])
+// per channel c: dz[n][c] = dgate[n][c] * g (1 - g) (stored for se_dh_part_kernel); db2[c] = sum_n dz;
+// dw2[c][s] = sum_n dz[n][c] * swish(h_pre[n][s])
 __global__ __launch_bounds__(256) void se_bwd_out_kernel(const float* __restrict__ dgate, int ldd, const float* __restrict__ gate, int ldg,
                                                          const float* __restrict__ h_pre, int N, int S, int C, float* __restrict__ dz,
                                                          float* __restrict__ dw2, float* __restrict__ db2) {
@@ -87,86 +131,80 @@ __global__ __launch_bounds__(256) void se_bwd_out_kernel(const float* __restrict
   }
   if (db2) db2[c] = sb;
   float* wr = dw2 + (size_t)c * S;
-  for (int s = 0; s < S; ++s) {
-    float t = 0.f;
+  if ((S & 3) == 0) {
+    for (int s = 0; s < S; s += 4) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int n = 0; n < SE_MAXN; ++n)
-      if (n < N) t = fmaf(d[n], hs[n * S + s], t);
-    wr[s] = t;
-  }
-}
-
-// per squeezed channel s (one wave): dh[n] = sum_c w2[c][s] * dz[n][c]; dhp[n][s] = dh[n] * swish'(h_pre[n][s]);
-// db1[s] = sum_n dhp; dw1[s][c] = sum_n dhp[n][s] * sq[n][c]
-__global__ __launch_bounds__(256) void se_bwd_hidden_kernel(const float* __restrict__ dz, const float* __restrict__ w2, const float* __restrict__ h_pre,
-                                                            const float* __restrict__ sq, int ldq, int N, int S, int C,
-                                                            float* __restrict__ dhp, float* __restrict__ dw1, float* __restrict__ db1) {
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= S) return;
-  float acc[SE_MAXN];
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-  for (int n = 0; n < SE_MAXN; ++n) acc[n] = 0.f;
-  for (int c = lane; c < C; c += 64) {
-    const float wv = w2[(size_t)c * S + s];
-#pragma unroll
-    for (int n = 0; n < SE_MAXN; ++n)
-      if (n < N) acc[n] = fmaf(wv, dz[(size_t)n * C + c], acc[n]);
-  }
-  float sb = 0.f;
-#pragma unroll
-  for (int n = 0; n < SE_MAXN; ++n)
-    if (n < N) {
-      acc[n] = wave_sum(acc[n]) * ssg_swish_grad(h_pre[n * S + s]);          // every lane holds the total
-      if (lane == 0) dhp[n * S + s] = acc[n];
-      sb += acc[n];
+        for (int n = 0; n < SE_MAXN; ++n)
+          if (n < N) t[e] = fmaf(d[n], hs[n * S + s + e], t[e]);
+      *(f32x4*)(wr + s) = t;
     }
-  if (lane == 0 && db1) db1[s] = sb;
-  for (int c = lane; c < C; c += 64) {
-    float t = 0.f;
+  } else {
+    for (int s = 0; s < S; ++s) {
+      float t = 0.f;
 #pragma unroll
-    for (int n = 0; n < SE_MAXN; ++n)
-      if (n < N) t = fmaf(acc[n], sq[(size_t)n * ldq + c], t);
-    dw1[(size_t)s * C + c] = t;
+      for (int n = 0; n < SE_MAXN; ++n)
+        if (n < N) t = fmaf(d[n], hs[n * S + s], t);
+      wr[s] = t;
+    }
   }
 }
 
-// per channel c: dsq[n][c] = sum_s w1[s][c] * dhp[n][s]
-__global__ __launch_bounds__(256) void se_bwd_in_kernel(const float* __restrict__ dhp, const float* __restrict__ w1, int N, int S, int C,
-                                                        float* __restrict__ dsq, int lds_) {
-  extern __shared__ float hs[];
-  for (int i = threadIdx.x; i < N * S; i += 256) hs[i] = dhp[i];
+// dhp[n][s] = (sum_b part[b][n][s]) * swish'(h_pre[n][s]); db1[s] = sum_n dhp (workgroup 0);
+// per channel c: dw1[s][c] = sum_n dhp[n][s] * sq[n][c];  dsq[n][c] = sum_s w1[s][c] * dhp[n][s]
+__global__ __launch_bounds__(256) void se_bwd_in_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ h_pre,
+                                                        const float* __restrict__ sq, int ldq, const float* __restrict__ w1, int N, int S, int C,
+                                                        float* __restrict__ dsq, int lds_, float* __restrict__ dw1, float* __restrict__ db1) {
+  extern __shared__ float hs[];                          // dhp [N][S]
+  for (int i = threadIdx.x; i < N * S; i += 256) {
+    hs[i] = sum_parts(part, nblk, N * S, i) * ssg_swish_grad(h_pre[i]);
+  }
   __syncthreads();
+  if (blockIdx.x == 0 && db1)
+    for (int s = threadIdx.x; s < S; s += 256) {
+      float t = 0.f;
+      for (int n = 0; n < N; ++n) t += hs[n * S + s];
+      db1[s] = t;
+    }
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  float acc[SE_MAXN];
+  float q[SE_MAXN], acc[SE_MAXN];
 #pragma unroll
-  for (int n = 0; n < SE_MAXN; ++n) acc[n] = 0.f;
+  for (int n = 0; n < SE_MAXN; ++n) { q[n] = n < N ? sq[(size_t)n * ldq + c] : 0.f; acc[n] = 0.f; }
+#pragma unroll 8
   for (int s = 0; s < S; ++s) {
     const float wv = w1[(size_t)s * C + c];
+    float t = 0.f;
 #pragma unroll
     for (int n = 0; n < SE_MAXN; ++n)
-      if (n < N) acc[n] = fmaf(wv, hs[n * S + s], acc[n]);
+      if (n < N) { const float dh = hs[n * S + s]; t = fmaf(dh, q[n], t); acc[n] = fmaf(wv, dh, acc[n]); }
+    dw1[(size_t)s * C + c] = t;
   }
 #pragma unroll
   for (int n = 0; n < SE_MAXN; ++n)
     if (n < N) dsq[(size_t)n * lds_ + c] = acc[n];
 }
 
-bool se_shape_ok(int N, int C, int S) { return N >= 1 && N <= SE_MAXN && S >= 1 && S <= 256 && N * S <= 4096 && C >= 1; }
+bool se_shape_ok(int N, int C, int S) { return N >= 1 && N <= SE_MAXN && S >= 1 && S <= 256 && N * S <= 2048 && C >= 1; }
 
 }  // namespace
 
 extern "C" int ssg_se_gate_ok(int N, int C, int S) { return se_shape_ok(N, C, S) ? 1 : 0; }
 
+// floats of scratch for either direction: one [N][S] partial per 64 channels, plus dz [N][C] in the backward
+extern "C" int64_t ssg_se_gate_workspace_floats(int N, int C, int S) { return (int64_t)((C + SE_CK - 1) / SE_CK) * N * S + (int64_t)N * C; }
+
 extern "C" int ssg_se_gate_fwd_f32(const float* sq, int ldq, int N, int C, const float* w1, const float* b1, const float* w2, const float* b2,
-                                   int S, float* h_pre, float* gate, int ldg, void* stream) {
-  SSG_REQUIRE(sq && w1 && w2 && h_pre && gate, SSG_EINVAL, "se_gate: null pointer");
-  SSG_REQUIRE(se_shape_ok(N, C, S) && ldq >= C && ldg >= C, SSG_EINVAL, "se_gate: N=%d C=%d S=%d outside the kernel's range (N <= 16, S <= 256, N*S <= 4096)", N, C, S);
+                                   int S, float* h_pre, float* gate, int ldg, float* tmp, void* stream) {
+  SSG_REQUIRE(sq && w1 && w2 && h_pre && gate && tmp, SSG_EINVAL, "se_gate: null pointer");
+  SSG_REQUIRE(se_shape_ok(N, C, S) && ldq >= C && ldg >= C, SSG_EINVAL, "se_gate: N=%d C=%d S=%d outside the kernel's range (N <= 16, S <= 256, N*S <= 2048)", N, C, S);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(se_hidden_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, sq, ldq, N, C, w1, b1, S, h_pre);
+  const int nck = (C + SE_CK - 1) / SE_CK;
+  hipLaunchKernelGGL(se_hidden_part_kernel, dim3((unsigned)((N * S + 255) / 256), (unsigned)nck), dim3(256), 0, st, sq, ldq, N, C, w1, S, tmp);
   SSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), (size_t)N * S * sizeof(float), st, h_pre, N, S, w2, b2, C, gate, ldg);
+  hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), (size_t)N * S * sizeof(float), st, (const float*)tmp, nck, b1, N, S, w2, b2, C, h_pre, gate, ldg);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -177,14 +215,16 @@ extern "C" int ssg_se_gate_bwd_f32(const float* dgate, int ldd, const float* gat
   SSG_REQUIRE(dgate && gate && h_pre && sq && w1 && w2 && dsq && dw1 && dw2 && tmp, SSG_EINVAL, "se_gate_bwd: null pointer");
   SSG_REQUIRE(se_shape_ok(N, C, S) && ldd >= C && ldg >= C && ldq >= C && lds_ >= C, SSG_EINVAL, "se_gate_bwd: N=%d C=%d S=%d outside the kernel's range", N, C, S);
   hipStream_t st = (hipStream_t)stream;
-  float* dz = tmp;                                       // [N][C]
-  float* dhp = tmp + (size_t)N * C;                      // [N][S]
+  const int nck = (C + SE_CK - 1) / SE_CK;
+  float* part = tmp;                                     // [nck][N][S]
+  float* dz = tmp + (size_t)nck * N * S;                 // [N][C]
   const size_t lds_bytes = (size_t)N * S * sizeof(float);
-  hipLaunchKernelGGL(se_bwd_out_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), lds_bytes, st, dgate, ldd, gate, ldg, h_pre, N, S, C, dz, dw2, db2);
+  const unsigned cblk = (unsigned)((C + 255) / 256);
+  hipLaunchKernelGGL(se_bwd_out_kernel, dim3(cblk), dim3(256), lds_bytes, st, dgate, ldd, gate, ldg, h_pre, N, S, C, dz, dw2, db2);
   SSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(se_bwd_hidden_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, (const float*)dz, w2, h_pre, sq, ldq, N, S, C, dhp, dw1, db1);
+  hipLaunchKernelGGL(se_dh_part_kernel, dim3((unsigned)((N * S + 255) / 256), (unsigned)nck), dim3(256), 0, st, (const float*)dz, N, C, w2, S, part);
   SSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(se_bwd_in_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), lds_bytes, st, (const float*)dhp, w1, N, S, C, dsq, lds_);
+  hipLaunchKernelGGL(se_bwd_in_kernel, dim3(cblk), dim3(256), lds_bytes, st, (const float*)part, nck, h_pre, sq, ldq, w1, N, S, C, dsq, lds_, dw1, db1);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

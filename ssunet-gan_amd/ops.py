@@ -1299,8 +1299,9 @@ class _SEGate(torch.autograd.Function):
         w1c = w1.detach().reshape(s_, c).contiguous(); w2c = w2.detach().reshape(c, s_).contiguous()
         h_pre = torch.empty((n, s_), dtype=torch.float32, device=dev)
         gate = new_nhwc(n, c, 1, 1, dev)
+        tmp = torch.empty(call('ssg_se_gate_workspace_floats', n, c, s_), dtype=torch.float32, device=dev)
         call('ssg_se_gate_fwd_f32', ptr(sq), _ld(sq), n, c, ptr(w1c), ptr(b1.detach()) if b1 is not None else None, ptr(w2c),
-             ptr(b2.detach()) if b2 is not None else None, s_, ptr(h_pre), ptr(gate), _ld(gate), stream_ptr())
+             ptr(b2.detach()) if b2 is not None else None, s_, ptr(h_pre), ptr(gate), _ld(gate), ptr(tmp), stream_ptr())
         ctx.save_for_backward(sq, w1c, w2c, h_pre, gate)
         ctx.cfg = (n, c, s_, tuple(w1.shape), tuple(w2.shape), b1 is not None, b2 is not None)
         return gate
@@ -1316,7 +1317,7 @@ class _SEGate(torch.autograd.Function):
         dw1 = torch.empty((s_, c), dtype=torch.float32, device=dev); dw2 = torch.empty((c, s_), dtype=torch.float32, device=dev)
         db1 = torch.empty(s_, dtype=torch.float32, device=dev) if has_b1 else None
         db2 = torch.empty(c, dtype=torch.float32, device=dev) if has_b2 else None
-        tmp = torch.empty(n * c + n * s_, dtype=torch.float32, device=dev)
+        tmp = torch.empty(call('ssg_se_gate_workspace_floats', n, c, s_), dtype=torch.float32, device=dev)
         call('ssg_se_gate_bwd_f32', ptr(dgate), _ld(dgate), ptr(gate), _ld(gate), ptr(h_pre), ptr(sq), _ld(sq), n, c, ptr(w1c), ptr(w2c), s_,
              ptr(dsq), _ld(dsq), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(tmp), stream_ptr())
         return dsq, dw1.reshape(shp1), db1, dw2.reshape(shp2), db2
