@@ -249,6 +249,20 @@ int ssg_bn_finalize_f32(const double* sums, double count, int C, const float* we
                         float eps, float momentum, int var_mode,
                         float* running_mean, float* running_var,
                         float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* Local (un-synchronised) batch norm in one call: the statistics passes finish with the per-channel constants and the running
+ * estimates of ssg_bn_finalize_f32 (same arithmetic, same bits), one launch less per batch-norm forward
+ * (archs.py:211,213, models_seg_gan.py:43, efficientnet_pytorch/model.py:75,80,90).  `count` of the from-partials form =
+ * pixels the partial rows cover. */
+typedef struct ssg_bn_fin {
+  const float* weight; const float* bias;     /* may be NULL (1 / 0) */
+  float eps, momentum; int var_mode;          /* var_mode as ssg_bn_finalize_f32 */
+  float* running_mean; float* running_var;    /* may be NULL */
+  float* mean; float* invstd; float* scale; float* shift;
+} ssg_bn_fin;
+int ssg_bn_stats_finalize_f32(const float* x, int64_t P, int C, int ld, const ssg_bn_fin* fin, void* ws, void* stream);
+int ssg_bn_stats_finalize_bf16(const void* x, int64_t P, int C, int ld, const ssg_bn_fin* fin, void* ws, void* stream);
+int ssg_bn_stats_from_partials_finalize_f32(const double* part, int rows, int C, double count, const ssg_bn_fin* fin, void* ws, void* stream);
 int ssg_bn_apply_f32(const float* x, int64_t P, int C, int ld, const float* scale, const float* shift,
                      const float* res, int ldr, int act, float slope, float* y, int ldy, void* stream);
 /* backward: g = dy masked by the activation (y>0 ? 1 : slope), dres = g (if wanted);

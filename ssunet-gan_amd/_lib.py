@@ -57,6 +57,14 @@ class WgradDesc(C.Structure):
 
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 
+
+class BnFin(C.Structure):
+    """include/ssunet_hip.h `ssg_bn_fin`."""
+    _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('eps', C.c_float), ('momentum', C.c_float), ('var_mode', C.c_int),
+                ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
+                ('mean', C.c_void_p), ('invstd', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p)]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES).  Must cover every symbol of
 # include/ssunet_hip.h; tests/test_abi_symbols.py cross-checks this table against the header.
 SIGNATURES = {
@@ -138,6 +146,9 @@ SIGNATURES = {
     'ssg_gemm_bf16': [_P, _L, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P],
     'ssg_gemm_wgrad_bf16_workspace_bytes': [_L, _I, _I],
     'ssg_gemm_wgrad_bf16': [_P, _I, _P, _I, _L, _I, _I, _P, _P, _L, _P],
+    'ssg_bn_stats_finalize_f32': [_P, _L, _I, _I, C.POINTER(BnFin), _P, _P],
+    'ssg_bn_stats_finalize_bf16': [_P, _L, _I, _I, C.POINTER(BnFin), _P, _P],
+    'ssg_bn_stats_from_partials_finalize_f32': [_P, _I, _I, _D, C.POINTER(BnFin), _P, _P],
     'ssg_se_gate_ok': [_I, _I, _I],
     'ssg_se_gate_workspace_floats': [_I, _I, _I],
     'ssg_se_gate_fwd_f32': [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],

@@ -192,13 +192,17 @@ class _BNAct(torch.autograd.Function):
         # count] vector is all-reduced between the two stages, the reference's sync formula clamp(var, eps)^-1/2 (var_mode 1)
         synced = ops._synced(group)
         ws = ops._ws(call('ssg_bn_workspace_bytes', p, c), dev)
-        sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-        call('ssg_bn_stats_bf16', ptr(x), p, c, ldx, ptr(sums), int(synced), ptr(ws), stream_ptr())
-        if synced:
-            ops._timed_all_reduce('sync_bn_fwd', sums, group)
         stats = torch.empty((4, c), dtype=torch.float32, device=dev)
-        call('ssg_bn_finalize_f32', ptr(sums), 0.0 if synced else float(p), c, ptr(weight), ptr(bias), eps, momentum, var_mode,
-             ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), stream_ptr())
+        if not synced and ops.BN_FUSED_FINALIZE:
+            fin = ops.bn_fin(weight, bias, eps, momentum, var_mode, running_mean, running_var, stats)
+            call('ssg_bn_stats_finalize_bf16', ptr(x), p, c, ldx, C.byref(fin), ptr(ws), stream_ptr())
+        else:
+            sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+            call('ssg_bn_stats_bf16', ptr(x), p, c, ldx, ptr(sums), int(synced), ptr(ws), stream_ptr())
+            if synced:
+                ops._timed_all_reduce('sync_bn_fwd', sums, group)
+            call('ssg_bn_finalize_f32', ptr(sums), 0.0 if synced else float(p), c, ptr(weight), ptr(bias), eps, momentum, var_mode,
+                 ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), stream_ptr())
         if running_mean is not None or running_var is not None:
             ops._STATS_EPOCH[0] += 1
         y = new_bf16(n, c, h, w, dev)

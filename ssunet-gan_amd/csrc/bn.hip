@@ -173,9 +173,42 @@ __global__ __launch_bounds__(RED_BLOCK) void modulate_bwd_sums_kernel(
 // row order, then the 32 lane sums are added in lane order -> fixed summation order (bitwise
 // reproducible), 1/32 of the serial chain of a one-thread-per-channel loop.
 constexpr int FIN_LANES = 32;
+
+// per-channel batch-norm constants from the fp64 sums (shared by bn_finalize_kernel and the fused second reduce stage, so that
+// the two routes give the same bits)
+struct BnFin {
+  const float* weight; const float* bias; float eps, momentum; int var_mode;
+  float* running_mean; float* running_var; float* mean; float* invstd; float* scale; float* shift;
+};
+
+__device__ __forceinline__ void bn_finalize_channel(int c, double s1, double s2, double count, const BnFin& f) {
+  // Every multiply-add below is an EXPLICIT fma: hipcc contracts a*b + c on its own (-ffp-contract=fast, and the backend
+  // does it per inlining context whatever the source pragmas say), so the two kernels that share this function gave
+  // running_var values one ulp apart until the fusion was spelled out (tests/test_round2_gpu.py compares a synchronised
+  // world-1 run, which finalizes in its own launch, with the local fused route bit for bit).
+  const double m = s1 / count;
+  double var = fma(-m, m, s2 / count);
+  if (var < 0) var = 0;
+  double is;
+  if (f.var_mode == 0) is = 1.0 / sqrt(var + (double)f.eps);
+  else is = 1.0 / sqrt(var < (double)f.eps ? (double)f.eps : var);
+  const float mf = (float)m, isf = (float)is;
+  f.mean[c] = mf; f.invstd[c] = isf;
+  const float w = f.weight ? f.weight[c] : 1.f, b = f.bias ? f.bias[c] : 0.f;
+  const float sc = w * isf;
+  f.scale[c] = sc; f.shift[c] = fmaf(-mf, sc, b);
+  if (f.running_mean) f.running_mean[c] = fmaf(f.momentum, mf, (1.f - f.momentum) * f.running_mean[c]);
+  if (f.running_var) {
+    const double unb = count > 1 ? var * count / (count - 1) : var;
+    f.running_var[c] = fmaf(f.momentum, (float)unb, (1.f - f.momentum) * f.running_var[c]);
+  }
+}
+
+// `fin.mean != nullptr`: a local (un-synchronised) batch norm finishes here -- mean / invstd / scale / shift and the running
+// estimates from the channel's two totals, one launch instead of final + finalize (`fin_count` = pixels).
 __global__ __launch_bounds__(32 * FIN_LANES) void col_reduce_final_kernel(const double* __restrict__ part, int parts, int C, int C4,
                                                                           double* __restrict__ sums, float* __restrict__ fsum,
-                                                                          double count_out) {
+                                                                          double count_out, BnFin fin, double fin_count) {
   __shared__ double red[2][FIN_LANES][32];
   const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -192,34 +225,17 @@ __global__ __launch_bounds__(32 * FIN_LANES) void col_reduce_final_kernel(const 
     for (int k = 0; k < FIN_LANES; ++k) { t1 += red[0][k][cl]; t2 += red[1][k][cl]; }
     if (sums) { sums[c] = t1; sums[C + c] = t2; }
     if (fsum) fsum[c] = (float)t1;
+    if (fin.mean) bn_finalize_channel(c, t1, t2, fin_count, fin);
   }
   // sync-BN: this rank's pixel count rides the vector that is all-reduced (ranks may hold different local batches)
   if (sums && count_out > 0 && blockIdx.x == 0 && threadIdx.x == 0) sums[2 * C] = count_out;
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count_arg, int C, const float* __restrict__ weight,
-                                   const float* __restrict__ bias, float eps, float momentum, int var_mode,
-                                   float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                                   float* shift) {
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count_arg, int C, BnFin fin) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double count = count_arg > 0 ? count_arg : sums[2 * C];
-  const double m = sums[c] / count;
-  double var = sums[C + c] / count - m * m;
-  if (var < 0) var = 0;
-  double is;
-  if (var_mode == 0) is = 1.0 / sqrt(var + (double)eps);
-  else is = 1.0 / sqrt(var < (double)eps ? (double)eps : var);
-  const float mf = (float)m, isf = (float)is;
-  mean[c] = mf; invstd[c] = isf;
-  const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
-  const float sc = w * isf;
-  scale[c] = sc; shift[c] = b - mf * sc;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
-  if (running_var) {
-    const double unb = count > 1 ? var * count / (count - 1) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-  }
+  bn_finalize_channel(c, sums[c], sums[C + c], count, fin);
 }
 
 template <typename T>
@@ -330,7 +346,7 @@ template <int MODE, typename T>
 int run_reduce(const T* x, const T* y, const T* dy, long long P, int C, int ldx, int ldy, int lddy,
                const float* scale, const float* shift,
                const float* mean, const float* invstd, int act, float slope, double* sums, float* fsum, void* ws,
-               hipStream_t st, double count_out = 0.0) {
+               hipStream_t st, double count_out = 0.0, BnFin fin = BnFin{}, double fin_count = 0.0) {
   constexpr int Q = SsgQ<T>::value;
   const RedGeom g = red_geom(P, C, Q);
   const int C4 = 4 * Q * ((C + 4 * Q - 1) / (4 * Q));
@@ -338,7 +354,7 @@ int run_reduce(const T* x, const T* y, const T* dy, long long P, int C, int ldx,
   hipLaunchKernelGGL((col_reduce_kernel<MODE, T>), dim3((unsigned)g.parts, (unsigned)g.groups), dim3(RED_BLOCK), 0, st, x, y, dy,
                      P, C, ldx, ldy, lddy, mean, invstd, scale, shift, act, slope, g.TQ, g.PR, g.rows_per_part, part);
   SSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C4, sums, fsum, count_out);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C4, sums, fsum, count_out, fin, fin_count);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -465,7 +481,7 @@ extern "C" int ssg_bn_stats_from_partials_f32(const double* part, int rows, int 
     SSG_LAUNCH_CHECK();
     src = (const double*)ws; nrows = nz;
   }
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, src, nrows, C, C, sums, (float*)nullptr, count);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, src, nrows, C, C, sums, (float*)nullptr, count, BnFin{}, 0.0);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -480,8 +496,48 @@ extern "C" int ssg_bn_finalize_f32(const double* sums, double count, int C, cons
                                    float eps, float momentum, int var_mode, float* running_mean, float* running_var,
                                    float* mean, float* invstd, float* scale, float* shift, void* stream) {
   SSG_REQUIRE(sums && mean && invstd && scale && shift && C > 0, SSG_EINVAL, "bn_finalize: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, (hipStream_t)stream, sums, count, C,
-                     weight, bias, eps, momentum, var_mode, running_mean, running_var, mean, invstd, scale, shift);
+  const BnFin fin{weight, bias, eps, momentum, var_mode, running_mean, running_var, mean, invstd, scale, shift};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, (hipStream_t)stream, sums, count, C, fin);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+// Local batch norm: statistics and finalize in one call (the second reduce stage finishes the channel) -- one launch less per
+// batch-norm forward than ssg_bn_stats_* + ssg_bn_finalize_f32, same bits.
+namespace {
+template <typename T>
+int bn_stats_finalize_impl(const T* x, int64_t P, int C, int ld, const ssg_bn_fin* f, void* ws, void* stream) {
+  SSG_REQUIRE(x && f && ws && P > 0 && C > 0 && f->mean && f->invstd && f->scale && f->shift, SSG_EINVAL, "bn_stats_finalize: bad args");
+  SSG_REQUIRE(C % (4 * SsgQ<T>::value) == 0 && ld % (4 * SsgQ<T>::value) == 0 && ld >= C && ssg_aligned16(x), SSG_EALIGN,
+              "bn_stats_finalize: C / ld must be multiples of 4 (fp32) or 8 (bf16), rows 16-byte aligned");
+  const BnFin fin{f->weight, f->bias, f->eps, f->momentum, f->var_mode, f->running_mean, f->running_var, f->mean, f->invstd, f->scale, f->shift};
+  return run_reduce<0, T>(x, nullptr, nullptr, P, C, ld, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, ws, (hipStream_t)stream,
+                          0.0, fin, (double)P);
+}
+}  // namespace
+
+extern "C" int ssg_bn_stats_finalize_f32(const float* x, int64_t P, int C, int ld, const ssg_bn_fin* fin, void* ws, void* stream) {
+  return bn_stats_finalize_impl<float>(x, P, C, ld, fin, ws, stream);
+}
+extern "C" int ssg_bn_stats_finalize_bf16(const void* x, int64_t P, int C, int ld, const ssg_bn_fin* fin, void* ws, void* stream) {
+  return bn_stats_finalize_impl<ssg_bf16>((const ssg_bf16*)x, P, C, ld, fin, ws, stream);
+}
+
+extern "C" int ssg_bn_stats_from_partials_finalize_f32(const double* part, int rows, int C, double count, const ssg_bn_fin* f, void* ws, void* stream) {
+  SSG_REQUIRE(part && f && ws && rows > 0 && C > 0 && count > 0 && f->mean && f->invstd && f->scale && f->shift, SSG_EINVAL,
+              "bn_stats_from_partials_finalize: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const BnFin fin{f->weight, f->bias, f->eps, f->momentum, f->var_mode, f->running_mean, f->running_var, f->mean, f->invstd, f->scale, f->shift};
+  const double* src = part; int nrows = rows;
+  if (rows > 4 * FOLD_Z) {
+    const int rpz = (rows + FOLD_Z - 1) / FOLD_Z;
+    const int nz = (rows + rpz - 1) / rpz;
+    hipLaunchKernelGGL(bnpart_fold_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)nz), dim3(256), 0, st, part, rows, C, rpz, (double*)ws);
+    SSG_LAUNCH_CHECK();
+    src = (const double*)ws; nrows = nz;
+  }
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, src, nrows, C, C, (double*)nullptr,
+                     (float*)nullptr, 0.0, fin, count);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -535,7 +591,7 @@ extern "C" int ssg_spade_modulate_bwd_sums_f32(const float* x, int ldx, const fl
                      (long long)P, C, dx, lddx, dgb, lddgb, g.TQ, g.PR, g.rows_per_part, part);
   SSG_LAUNCH_CHECK();
   // sums[0:C] = sum dgamma, sums[C:2C] = sum dbeta (ssg_bn_workspace_bytes(P, C) bytes of workspace)
-  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C, sums, nullptr, 0.0);
+  hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(32 * FIN_LANES), 0, st, part, g.parts, C, C, sums, nullptr, 0.0, BnFin{}, 0.0);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -600,6 +600,21 @@ def _synced(group):
 _STATS_EPOCH = [0]
 
 
+BN_FUSED_FINALIZE = _os.environ.get('SSG_BN_FUSED_FINALIZE', '1') != '0'
+
+
+def bn_fin(weight, bias, eps, momentum, var_mode, running_mean, running_var, stats):
+    """ctypes `ssg_bn_fin` over the given tensors (stats = [mean, invstd, scale, shift] rows)."""
+    f = _lib.BnFin()
+    f.weight = weight.data_ptr() if weight is not None else None
+    f.bias = bias.data_ptr() if bias is not None else None
+    f.eps = eps; f.momentum = momentum; f.var_mode = var_mode
+    f.running_mean = running_mean.data_ptr() if running_mean is not None else None
+    f.running_var = running_var.data_ptr() if running_var is not None else None
+    f.mean = stats[0].data_ptr(); f.invstd = stats[1].data_ptr(); f.scale = stats[2].data_ptr(); f.shift = stats[3].data_ptr()
+    return f
+
+
 def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part=None):
     """Timed wrapper (bench.py `hbm_stages`): algorithmic bytes per SURVEY.md 8(d) -- 2 reads + 1 write of the tensor, one read
     less when the statistics rode the producing conv's epilogue, one more for a residual."""
@@ -619,22 +634,35 @@ def _bn_fwd_body(x, weight, bias, running_mean, running_var, res, eps, momentum,
     p = n * h * w
     dev = x.device
     synced = _synced(group)
-    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-    if part is not None and part.numel() > 0:
-        # (sum x, sum x^2) came out of the producing conv's epilogue, one row per tile: x is not read for its statistics
-        if part.shape[-1] != c or part.numel() % (2 * c):
-            raise ValueError('batch_norm: statistics partials %s do not fit C=%d' % (tuple(part.shape), c))
-        rows = part.numel() // (2 * c)
-        ws = _ws(call('ssg_bn_stats_from_partials_workspace_bytes', rows, c), dev)
-        call('ssg_bn_stats_from_partials_f32', ptr(part), rows, c, ptr(sums), float(p) if synced else 0.0, ptr(ws), stream_ptr())
-    else:
-        ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
-        call('ssg_bn_stats_f32', ptr(x), p, c, _ld(x), ptr(sums), int(synced), ptr(ws), stream_ptr())
-    if synced:
-        _timed_all_reduce('sync_bn_fwd', sums, group)
     stats = torch.empty((4, c), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
-    call('ssg_bn_finalize_f32', ptr(sums), 0.0 if synced else float(p), c, ptr(weight), ptr(bias), eps, momentum, var_mode,
-         ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), stream_ptr())
+    have_part = part is not None and part.numel() > 0
+    if have_part and (part.shape[-1] != c or part.numel() % (2 * c)):
+        raise ValueError('batch_norm: statistics partials %s do not fit C=%d' % (tuple(part.shape), c))
+    if not synced and BN_FUSED_FINALIZE:
+        # local batch norm: the second reduce stage finishes the channel (one launch less; same bits as stats + finalize)
+        fin = bn_fin(weight, bias, eps, momentum, var_mode, running_mean, running_var, stats)
+        if have_part:
+            rows = part.numel() // (2 * c)
+            ws = _ws(call('ssg_bn_stats_from_partials_workspace_bytes', rows, c), dev)
+            call('ssg_bn_stats_from_partials_finalize_f32', ptr(part), rows, c, float(p), C.byref(fin), ptr(ws), stream_ptr())
+        else:
+            ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
+            call('ssg_bn_stats_finalize_f32', ptr(x), p, c, _ld(x), C.byref(fin), ptr(ws), stream_ptr())
+        sums = None
+    else:
+        sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+        if have_part:
+            # (sum x, sum x^2) came out of the producing conv's epilogue, one row per tile: x is not read for its statistics
+            rows = part.numel() // (2 * c)
+            ws = _ws(call('ssg_bn_stats_from_partials_workspace_bytes', rows, c), dev)
+            call('ssg_bn_stats_from_partials_f32', ptr(part), rows, c, ptr(sums), float(p) if synced else 0.0, ptr(ws), stream_ptr())
+        else:
+            ws = _ws(call('ssg_bn_workspace_bytes', p, c), dev)
+            call('ssg_bn_stats_f32', ptr(x), p, c, _ld(x), ptr(sums), int(synced), ptr(ws), stream_ptr())
+        if synced:
+            _timed_all_reduce('sync_bn_fwd', sums, group)
+        call('ssg_bn_finalize_f32', ptr(sums), 0.0 if synced else float(p), c, ptr(weight), ptr(bias), eps, momentum, var_mode,
+             ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), stream_ptr())
     if running_mean is not None or running_var is not None:
         _STATS_EPOCH[0] += 1
     y = new_nhwc(n, c, h, w, dev)

@@ -64,3 +64,26 @@ def test_se_gate_matches_the_two_convs(pkg, dev, n, c, s):
     close(exp.weight.grad, w2.grad, 'dw2'); close(exp.bias.grad, b2.grad, 'db2')
     # outside the range the caller keeps the conv path
     assert pkg.ops.se_gate(torch.randn(17, c, 1, 1, device=dev), red, exp) is None
+
+
+def test_fused_statistics_finalize_gives_the_bits_of_the_two_launch_route(pkg, dev):
+    """ssg_bn_stats_finalize_f32 / ssg_bn_stats_from_partials_finalize_f32 (local batch norm: the second reduce stage finishes the
+    channel) against ssg_bn_stats_* + ssg_bn_finalize_f32: outputs, constants and running estimates bit for bit."""
+    ops = pkg.ops
+    torch.manual_seed(0)
+    saved = ops.BN_FUSED_FINALIZE
+    try:
+        for (n, c, hw, var_mode) in [(6, 64, 32, 1), (2, 128, 64, 0), (3, 40, 17, 0)]:
+            x = ops.to_nhwc((torch.randn(n, c, hw, hw) * 0.7 + 0.3).to(dev))
+            w = torch.rand(c, device=dev) + 0.5; b = torch.randn(c, device=dev)
+            outs = []
+            for fused in (True, False):
+                ops.BN_FUSED_FINALIZE = fused
+                rm = torch.randn(c, device=dev, generator=torch.Generator(device=dev).manual_seed(3)); rv = torch.rand(c, device=dev, generator=torch.Generator(device=dev).manual_seed(4)) + 0.5
+                y, stats, cnt = ops._bn_fwd_body(x, w, b, rm, rv, None, 1e-5, 0.1, 0, 0.0, var_mode, None)
+                assert cnt is None
+                outs.append((y.clone(), stats.clone(), rm.clone(), rv.clone()))
+            for a, bb, name in zip(outs[0], outs[1], ('y', 'stats', 'running_mean', 'running_var')):
+                assert torch.equal(a, bb), '%s differs between the fused and the two-launch route (C=%d)' % (name, c)
+    finally:
+        ops.BN_FUSED_FINALIZE = saved
