@@ -84,3 +84,35 @@ def test_fused_spade_entry_rejects_unsupported_descriptors(pkg):
     assert lib.call('ssg_conv2d_workspace_bytes', ctypes.byref(d)) == 0
     rc = lib.load().ssg_spade_conv_modulate_f32(ctypes.byref(d), None, 0, None, 0, None)
     assert rc != 0 and b'spade_conv_modulate' in lib.load().ssg_last_error()
+
+
+def test_struct_sizes_and_offsets_match_the_c_compiler(pkg, tmp_path):
+    """The three structs that cross the boundary by pointer (ssg_conv_desc, ssg_wgrad_desc, ssg_bn_fin): size and every field
+    offset as gcc lays the header out == what the ctypes mirrors in _lib.py say (a maintainer's cgo / ctypes stub binds the
+    header, the package binds the mirrors: both must describe the same bytes)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    lib = pkg._lib
+    structs = (('ssg_conv_desc', lib.ConvDesc), ('ssg_wgrad_desc', lib.WgradDesc), ('ssg_bn_fin', lib.BnFin))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HEADER, 'int main(void) {']
+    for cname, mirror in structs:
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in mirror._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c99', '-o', str(exe), str(src)], check=True, capture_output=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, mirror in structs:
+        assert int(out[cname]) == ctypes.sizeof(mirror), (cname, out[cname], ctypes.sizeof(mirror))
+        for f in mirror._fields_:
+            assert int(out['%s.%s' % (cname, f[0])]) == getattr(mirror, f[0]).offset, (cname, f[0])
+    # field names of ssg_bn_fin in header order
+    hdr = open(HEADER).read()
+    body = hdr[hdr.index('typedef struct ssg_bn_fin {'):hdr.index('} ssg_bn_fin;')]
+    names = re.findall(r'(\w+)\s*[;,]', re.sub(r'/\*.*?\*/', '', body, flags=re.S))
+    assert names == [f[0] for f in lib.BnFin._fields_], names
