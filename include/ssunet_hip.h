@@ -79,6 +79,12 @@ typedef struct {
   float* ws; int64_t ws_bytes;  /* optional split-K workspace (ssg_conv2d_workspace_bytes(d) bytes, 16-byte aligned); NULL = never split */
   const void* w_split;      /* optional: the same weights split into three bf16 terms by ssg_pack_weights_split_bf16x3 for the column
                              * tile ssg_conv2d_split_bn(d) reports; non-NULL selects the split-operand kernel (below).  NULL = fp32 MFMA */
+  int parity_merge;         /* 1 = the launch is the whole input gradient of a 3x3 stride-2 pad-1 conv (models_seg_gan.py:37-39, s2 blocks):
+                             * its 9 taps are the four output-parity classes in the order (0,0) | (0,1) x2 | (1,0) x2 | (1,1) x4, tap t of
+                             * class (py, px) accumulates into output pixel (2 gy + py, 2 gx + px); GH x GW = ceil(OH/2) x ceil(OW/2),
+                             * out_sy = out_sx = 2, out_oy = out_ox = 0, no bias / res / bnpart, w_split for a 64-column tile.  Only
+                             * where ssg_conv2d_split_bn(d) returns 64 for such a descriptor; otherwise the caller launches the classes
+                             * one by one (parity_merge = 0, ntaps = 1 / 2 / 2 / 4, out_oy / out_ox = the class).  0 = plain conv. */
 } ssg_conv_desc;
 
 /* fp32 convolution on the bf16 matrix pipe (3x3, unit stride; archs.py:210,212 and their input gradients, models_seg_gan.py:37-39

@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ('act', C.c_int), ('slope', C.c_float),
         ('bnpart', C.c_void_p),
         ('ws', C.c_void_p), ('ws_bytes', C.c_int64),
-        ('w_split', C.c_void_p),
+        ('w_split', C.c_void_p), ('parity_merge', C.c_int),
     ]
 
 
@@ -182,7 +182,7 @@ _RESTYPES = {
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_split_bn', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
                                 'ssg_spade_conv_modulate_ok', 'ssg_se_gate_ok'}
 
-ABI_VERSION = 5          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
+ABI_VERSION = 6          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
 
 _lib = None
 

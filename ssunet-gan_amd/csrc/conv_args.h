@@ -18,6 +18,7 @@ struct ConvArgs {
   int tiles_x, tiles_y, nsteps;
   int ntiles_n, xcd_swizzle;     // conv_igemm_dma.hip: Cout tiles (fastest workgroup index), XCD-contiguous tile map
   float* ws; int ksplit;         // conv_igemm_halo.hip: split-K slabs [ksplit][N*GH*GW][pad4(Cout)] (ksplit <= 1: off)
+  int parity;                    // ssg_conv_desc.parity_merge
 };
 
 
@@ -36,6 +37,8 @@ int ssg_conv_halo_ksplit(const ConvArgs& a, int variant);    // split-K slabs th
 bool ssg_conv_halo_x3_ok(const ConvArgs& a, int variant);
 int ssg_conv_halo_x3_bn(const ConvArgs& a, int variant);      // column tile (64 / 128) the weights must be split-packed for
 int ssg_conv_igemm_halo_x3_launch(const ConvArgs& a, int variant, hipStream_t st);
+bool ssg_conv_halo_x3_parity_ok(const ConvArgs& a);          // the four parity classes of a 3x3 stride-2 input gradient as one launch
+int ssg_conv_igemm_halo_x3_parity_launch(const ConvArgs& a, hipStream_t st);
 // conv_igemm_dma_x3.hip: the LDS-DMA pipeline (1x1, stride 2, parity classes) with split operands; column tile 128 / 64 or 0 = not eligible
 int ssg_conv_dma_x3_bn(const ConvArgs& a);
 int ssg_conv_igemm_dma_x3_launch(const ConvArgs& a, hipStream_t st);

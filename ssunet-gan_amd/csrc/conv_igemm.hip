@@ -291,6 +291,7 @@ ConvArgs to_args(const ssg_conv_desc* d) {
   a.nsteps = d->Kp / 16;
   a.tiles_x = a.tiles_y = 0;
   a.ws = nullptr; a.ksplit = 1;
+  a.parity = d->parity_merge;
   return a;
 }
 
@@ -298,6 +299,7 @@ ConvArgs to_args(const ssg_conv_desc* d) {
 int split_bn(const ssg_conv_desc* d) {
   if (!uses_dma(d) || d->Cout <= 32) return 0;
   const ConvArgs a = to_args(d);
+  if (d->parity_merge) return ssg_conv_halo_x3_parity_ok(a) ? 64 : 0;
   if (!uses_halo(a)) return ssg_conv_dma_x3_bn(a);            // 1x1, stride 2, parity-class launches: the LDS-DMA pipeline
   if (!ssg_conv_halo_x3_ok(a, pick_variant(d))) return 0;
   if (d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) && ssg_conv_halo_ksplit(a, pick_variant(d)) > 1) return 0;   // small grids keep split-K
@@ -358,10 +360,13 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
     if (need > 0 && d->ws_bytes >= need && !((uintptr_t)d->ws & 15)) { a.ws = d->ws; a.ksplit = k; }
   }
   SSG_REQUIRE(!d->bnpart || uses_dma(d), SSG_EINVAL, "conv: bnpart given but this shape has no statistics epilogue (ssg_conv2d_bnpart_rows == 0)");
+  SSG_REQUIRE(!d->parity_merge || (d->w_split && split_bn(d) == 64), SSG_EINVAL,
+              "conv: parity_merge needs a descriptor for which ssg_conv2d_split_bn reports 64 and its w_split pack");
   if (uses_dma(d)) {
     if (d->w_split && split_bn(d) > 0) {                 // operands split into bf16 terms on the bf16 matrix pipe
       SSG_REQUIRE(ssg_aligned16(d->w_split), SSG_EALIGN, "conv: w_split alignment");
       a.w = (const float*)d->w_split; a.ws = nullptr; a.ksplit = 1;
+      if (d->parity_merge) return ssg_conv_igemm_halo_x3_parity_launch(a, st);
       if (!uses_halo(a)) return ssg_conv_igemm_dma_x3_launch(a, st);
       return ssg_conv_igemm_halo_x3_launch(a, pick_variant(d), st);
     }
@@ -396,6 +401,9 @@ extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
 extern "C" int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc != SSG_OK) return rc;
+  SSG_REQUIRE(!d->parity_merge || ssg_conv2d_split_bn(d) == 64, SSG_EINVAL,
+              "conv: parity_merge on a descriptor that has no merged-parity kernel (ssg_conv2d_split_bn != 64)");
+  if (d->parity_merge) return ssg_conv2d_igemm_f32(d, stream);
   const int k4 = ssg_thin4_conv_kind(d);
   const int k = k4 ? 0 : ssg_thin_conv_kind(d);
   SSG_REQUIRE(!d->bnpart || !(k4 || k), SSG_EINVAL, "conv: bnpart given but this shape has no statistics epilogue (ssg_conv2d_bnpart_rows == 0)");

@@ -208,9 +208,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3r_kernel(const ConvA
 // VALU per step; SQ counters of round 3: 2.7 VALU per MFMA, MFMA busy 61 %).  The fp32 image is single-buffered (the DMA of
 // chunk c + 1 is issued after chunk c has been converted); a chunk boundary costs one conversion pass (2 x 13 KB read, 19 KB
 // written by 256 threads) and one extra barrier per 9 steps.  LDS: 13 KB fp32 image + 20 KB split image + 3 weight stages + 1 KB.
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_halo_x3_kernel(const ConvArgs a) {
+// PARITY: the four parity classes of a 3x3 stride-2 input gradient in ONE launch.  Output pixel
+// (2gy + py, 2gx + px) of class (py, px) sums 1 / 2 / 2 / 4 taps of the SAME 2x2 neighbourhood of dy around (gy, gx), so the four
+// launches of the LDS-DMA kernel (which gathered dy once per tap and class, K = 1..4 taps deep: prologue-bound) become the nine tap
+// steps of one halo tile accumulating into four accumulator sets -- tap t belongs to class 0 | 1 1 | 2 2 | 3 3 3 3, the order
+// ops._conv_dgrad_impl packs them in -- and four strided epilogues.  4 x 32 registers of accumulators: BN = 64 only.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PARITY = false>
+__global__ __launch_bounds__(256, (BN == 64 && !PARITY) ? 3 : 2) void conv_igemm_halo_x3_kernel(const ConvArgs a) {
   static_assert(BM == 128, "4 rows of 32 pixels");
+  static_assert(!PARITY || (BN == 64 && WAVES_M == 4), "the merged parity form is the 4 x 1 layout on 64 columns");
+  constexpr int NCLS = PARITY ? 4 : 1;
   constexpr int TWL = 5, TW = 32, TH = 4;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / 32, NI = WTN / 32;
@@ -292,13 +299,15 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_halo_x3_kern
     }
   };
 
-  f32x16 acc[MI][NI];
+  f32x16 acc[NCLS][MI][NI];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int q = 0; q < NCLS; ++q)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
 
   const int half = lane >> 5, l31 = lane & 31;
   int rb[MI];
@@ -382,10 +391,11 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_halo_x3_kern
         b2[j] = *(const bf16x8*)(row + 16 * ((2 + half) ^ bf[j]));
         b3[j] = *(const bf16x8*)(row + 16 * ((4 + half) ^ bf[j]));
       }
+      const int cls = PARITY ? (t < 1 ? 0 : (t < 3 ? 1 : (t < 5 ? 2 : 3))) : 0;        // constant after unrolling
 #define SSG_X3_TERM(A, B)                                                                           \
   _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
   _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[i][j], 0, 0, 0);
+      acc[cls][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[cls][i][j], 0, 0, 0);
       SSG_X3_TERM(a3, b1) SSG_X3_TERM(a2, b2) SSG_X3_TERM(a1, b3)
       SSG_X3_TERM(a2, b1) SSG_X3_TERM(a1, b2)
       SSG_X3_TERM(a1, b1)
@@ -400,7 +410,17 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_halo_x3_kern
     ssg_probe_buf_x3[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - pr0;
   }
 #endif
-  ssg_halo_epilogue<BM, BN, WAVES_M, WAVES_N, TWL, false>(a, acc, lds, n, ty, tx, n0, 0, wm, wn, half, l31);
+  if constexpr (PARITY) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ConvArgs b = a;                                    // class (py, px) = (q >> 1, q & 1): its own grid extent and output phase
+      b.out_oy = q >> 1; b.out_ox = q & 1;
+      b.GH = (a.OH - (q >> 1) + 1) >> 1; b.GW = (a.OW - (q & 1) + 1) >> 1;
+      ssg_halo_epilogue<BM, BN, WAVES_M, WAVES_N, TWL, false>(b, acc[q], lds, n, ty, tx, n0, 0, wm, wn, half, l31);
+    }
+  } else {
+    ssg_halo_epilogue<BM, BN, WAVES_M, WAVES_N, TWL, false>(a, acc[0], lds, n, ty, tx, n0, 0, wm, wn, half, l31);
+  }
 }
 
 // fp32 packed [R][Kp] (kmode 0: k = step*16 + c) -> split tiles [ceil(R/BN)][nsteps][BN][96 B]; one thread per (row, step, k-half)
@@ -450,7 +470,7 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   return SSG_OK;
 }
 
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BN, int WAVES_M, int WAVES_N, bool PARITY = false>
 int launch_p(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
   constexpr int TW = 32, TH = 4;
@@ -463,9 +483,9 @@ int launch_p(const ConvArgs& a0, hipStream_t st) {
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
   constexpr int lds_bytes = AP * 1024 + ((AP * 16 * XROW + 1023) / 1024) * 1024 + 3 * BN * XROW + 1024;
   static_assert(lds_bytes <= 80 * 1024, "two workgroups per CU");
-  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_halo_x3_kernel<128, BN, WAVES_M, WAVES_N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_igemm_halo_x3_kernel<128, BN, WAVES_M, WAVES_N, PARITY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (attr != hipSuccess) { ssg_set_error("conv halo x3: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
-  hipLaunchKernelGGL((conv_igemm_halo_x3_kernel<128, BN, WAVES_M, WAVES_N>), grid, dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_igemm_halo_x3_kernel<128, BN, WAVES_M, WAVES_N, PARITY>), grid, dim3(256), lds_bytes, st, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -496,6 +516,23 @@ bool ssg_conv_halo_x3_ok(const ConvArgs& a, int variant) {
   if (bytes > 0xfffffff0ull) return false;                    // 32-bit byte offsets of the buffer descriptors
   return a.Cout % bn == 0;
 }
+
+// merged parity classes of a 3x3 stride-2 input gradient: 9 taps with dy offsets in {0,1}^2 in class order, unit input stride,
+// output stride 2 from phase (0,0), the grid of class (0,0) (the largest), whole 64-column tiles, no bias / residual / statistics
+bool ssg_conv_halo_x3_parity_ok(const ConvArgs& a) {
+  static const int on = [] { const char* e = getenv("SSG_X3_PARITY"); return e ? atoi(e) : 1; }();
+  if (!on || !a.parity || a.kmode != 0 || a.ntaps != 9 || a.in_sy != 1 || a.in_sx != 1 || a.out_sy != 2 || a.out_sx != 2 || a.out_oy || a.out_ox) return false;
+  if (a.GH != (a.OH + 1) / 2 || a.GW != (a.OW + 1) / 2 || a.Cout % 64 || a.bias || a.res || a.bnpart) return false;
+  static const int want[9][2] = {{0, 0}, {0, 1}, {0, 0}, {1, 0}, {0, 0}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};   // (dy, dx) per tap
+  for (int t = 0; t < 9; ++t) {
+    const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
+    if ((tb & 7) - 2 != want[t][0] || (tb >> 3) - 2 != want[t][1]) return false;
+  }
+  const unsigned long long bytes = (unsigned long long)a.N * a.H * a.W * (unsigned long long)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4ull;
+  return bytes <= 0xfffffff0ull && a.W >= 17;               // 32-bit buffer offsets; 32-wide tiles
+}
+
+int ssg_conv_igemm_halo_x3_parity_launch(const ConvArgs& a, hipStream_t st) { return launch_p<64, 4, 1, true>(a, st); }
 
 int ssg_conv_igemm_halo_x3_launch(const ConvArgs& a, int variant, hipStream_t st) {
   // wave layout: 4 x 1 (each wave one 32-pixel tile row x all BN columns) splits each activation fragment once per

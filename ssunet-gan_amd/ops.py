@@ -263,9 +263,11 @@ class _Timed(object):
 
 
 def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps, n, h, w, gh, gw, oh, ow,
-                 in_s, out_s, out_oy, out_ox, out, want_bn=False, tag=None):
+                 in_s, out_s, out_oy, out_ox, out, want_bn=False, tag=None, parity_merge=False):
     """Returns None, or -- with want_bn and a kernel that has the statistics epilogue -- the fp64 tensor [rows, 2, cout] of
-    per-tile (sum, sum of squares) of the conv output (ssg_conv_desc.bnpart)."""
+    per-tile (sum, sum of squares) of the conv output (ssg_conv_desc.bnpart).  parity_merge: the nine taps are the four parity
+    classes of a 3x3 stride-2 input gradient (ssg_conv_desc.parity_merge); returns False, with nothing launched, when the library
+    has no merged kernel for this shape."""
     d = ConvDesc()
     d.in1 = x1.data_ptr(); d.C1 = pad4(x1.shape[1]); d.ld1 = _ld(x1)
     if x2 is not None:
@@ -289,7 +291,10 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     d.bnpart = None
     d.ws = None; d.ws_bytes = 0
     d.w_split = None
+    d.parity_merge = 1 if parity_merge else 0
     split = None
+    if parity_merge and not (MFMA_SPLIT and kmode == 0 and call('ssg_conv2d_split_bn', C.byref(d)) == 64):
+        return False
     if MFMA_SPLIT and kmode == 0:      # decided first: the split-operand kernel has its own tile geometry (bnpart rows)
         bn = call('ssg_conv2d_split_bn', C.byref(d))
         if bn:
@@ -311,7 +316,9 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     label = None
     if PROFILE is not None:
         label = _CONV_LABELS.get(call('ssg_conv2d_kernel_id', C.byref(d)), '?') + ('+splitk' if ws is not None else '')
-        if split is not None:
+        if parity_merge:
+            label = 'conv_igemm_halo_x3_kernel<128,64,4,1,true>'
+        elif split is not None:
             if 'halo' in label:
                 label = label.replace('conv_igemm_halo_kernel', 'conv_igemm_halo_x3_kernel').replace('<256,64>', '<128,64>')
             else:
@@ -330,6 +337,8 @@ BN_EPILOGUE = _os.environ.get('SSG_BN_EPILOGUE', '1') != '0'
 # three bf16 terms (csrc/conv_igemm_halo_x3.hip: the error against fp64 is that of the fp32-MFMA kernel, tests/test_split_gpu.py;
 # 16/6 of the fp32 MFMA rate).  SSG_MFMA_SPLIT=0 keeps them on v_mfma_f32_32x32x2_f32 (conv_igemm_halo.hip).
 MFMA_SPLIT = _os.environ.get('SSG_MFMA_SPLIT', '1') == '1'
+# SSG_PARITY_MERGE=0: the input gradient of a 3x3 stride-2 conv as four launches (one per output parity class) again
+PARITY_MERGE = _os.environ.get('SSG_PARITY_MERGE', '1') != '0'
 
 
 def _split_pack(wpk, row0, rows, kp, bn):
@@ -405,6 +414,14 @@ def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None, wscale
             taps = [(ky, kx, (py + pt - ky) // s, (px + pl - kx) // s) for ky in range(kh) for kx in range(kw)
                     if (py + pt - ky) % s == 0 and (px + pl - kx) % s == 0]
             classes.append((py, px, taps))
+    if PARITY_MERGE and s == 2 and kh == 3 and kw == 3 and (pt, pl) == (1, 1) and MFMA_SPLIT:
+        # the four classes read the same 2x2 neighbourhood of dy: one launch, nine tap steps, four accumulator sets
+        # (conv_igemm_halo_x3_kernel<..., PARITY>); falls through to the per-class launches where the library declines
+        merged = [t for _, _, taps in classes for t in taps]
+        wpk, kp, kmode = _pack(weight, 1, merged, cred_pad, cred_pad, sigma=wscale)
+        if _conv_launch(dy, None, wpk, kp, kmode, c_lo, c_hi - c_lo, None, None, ACT_NONE, 0.0, merged, n, oh, ow,
+                        (h + 1) // 2, (w + 1) // 2, h, w, 1, s, 0, 0, dx, parity_merge=True) is not False:
+            return dx
     if any(len(t) == 0 for _, _, t in classes):
         dx.zero_()
     for py, px, taps in classes:

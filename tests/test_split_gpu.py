@@ -167,3 +167,38 @@ def test_split_dma_family_matches_fp64_like_fp32_mfma(pkg, dev, cin, co, hw, k, 
     ew32 = (w32 - wref).abs(); ew3 = (w3 - wref).abs()
     assert ew3.max().item() <= 2.0 * ew32.max().item() + 1e-6 * wref.abs().max().item(), (ew3.max().item(), ew32.max().item())
     assert ew3.pow(2).mean().sqrt().item() <= 2.0 * ew32.pow(2).mean().sqrt().item() + 1e-8
+
+
+@pytest.mark.parametrize('cin,co,h,w,nb', [(64, 64, 96, 128, 3), (128, 256, 63, 65, 2), (192, 64, 34, 40, 2), (64, 48, 31, 33, 1)])
+def test_merged_parity_input_gradient_of_stride2_conv(pkg, dev, cin, co, h, w, nb):
+    """conv_igemm_halo_x3_kernel<..., PARITY>: the four output-parity classes of a 3x3 stride-2 pad-1 input gradient as ONE launch
+    (models_seg_gan.py:37-39, the s2 blocks of D), against fp64 and against the four per-class launches; odd image sizes give
+    the classes unequal grids."""
+    ops = pkg.ops
+    torch.manual_seed(29)
+    torch.set_num_threads(16)
+    wc = torch.randn(co, cin, 3, 3) / (3 * cin ** 0.5)
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dyc = torch.randn(nb, co, oh, ow)
+    gref = torch.nn.grad.conv2d_input((nb, cin, h, w), wc.double(), dyc.double(), 2, 1)
+    dy = ops.to_nhwc(dyc.to(dev)); wd = wc.to(dev)
+    saved = ops.PARITY_MERGE
+
+    def run(merge):
+        ops.PARITY_MERGE = merge
+        ops.PROFILE = []
+        try:
+            g = ops._conv_dgrad_impl(dy, wd, 2, 1, h, w, 0, cin).cpu().double()
+            return g, [p[0] for p in ops.PROFILE]
+        finally:
+            ops.PROFILE = None
+            ops.PARITY_MERGE = saved
+    g1, l1 = _run(ops, True, lambda: run(True))
+    g4, l4 = _run(ops, True, lambda: run(False))
+    g32, _ = _run(ops, False, lambda: run(False))
+    assert l1 == ['conv_igemm_halo_x3_kernel<128,64,4,1,true>'], l1
+    assert len(l4) == 4, l4
+    e1 = (g1 - gref).abs().max().item(); e4 = (g4 - gref).abs().max().item(); e32 = (g32 - gref).abs().max().item()
+    assert e1 <= 2.0 * e32 + 1e-6, (e1, e32)
+    assert e1 <= 2.0 * e4 + 1e-6, (e1, e4)
+    assert (g1 - gref).pow(2).mean().sqrt().item() <= 2.0 * (g32 - gref).pow(2).mean().sqrt().item() + 1e-8
