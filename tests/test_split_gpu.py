@@ -202,3 +202,24 @@ def test_merged_parity_input_gradient_of_stride2_conv(pkg, dev, cin, co, h, w, n
     assert e1 <= 2.0 * e32 + 1e-6, (e1, e32)
     assert e1 <= 2.0 * e4 + 1e-6, (e1, e4)
     assert (g1 - gref).pow(2).mean().sqrt().item() <= 2.0 * (g32 - gref).pow(2).mean().sqrt().item() + 1e-8
+
+
+def test_merged_parity_declines_narrow_images(pkg, dev):
+    """dy narrower than 17 pixels (no 32-wide halo tile): ssg_conv2d_split_bn reports no merged kernel and the four per-class
+    launches run; the result is the same input gradient."""
+    ops = pkg.ops
+    torch.manual_seed(31)
+    cin, co, h, w, nb = 64, 64, 24, 30, 2
+    wc = torch.randn(co, cin, 3, 3) / (3 * cin ** 0.5)
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    assert ow < 17
+    dyc = torch.randn(nb, co, oh, ow)
+    gref = torch.nn.grad.conv2d_input((nb, cin, h, w), wc.double(), dyc.double(), 2, 1)
+    ops.PROFILE = []
+    try:
+        g = _run(ops, True, lambda: ops._conv_dgrad_impl(ops.to_nhwc(dyc.to(dev)), wc.to(dev), 2, 1, h, w, 0, cin)).cpu().double()
+        labels = [p[0] for p in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert len(labels) == 4 and not any('true' in l for l in labels), labels
+    assert (g - gref).abs().max().item() < 2e-5
