@@ -212,3 +212,67 @@ def test_efficientnet_b4_1024_bf16_config4(pkg, dev):
     for i in range(len(errs) - 1):
         assert errs[i + 1] < 1.35 * errs[i] + 5e-3, 'jump after block %d: %.4f -> %.4f' % (i, errs[i], errs[i + 1])
     assert errs[-1] < 0.3
+
+
+# ----------------------------------------------------------------------------- per-kernel: bf16 instantiation vs the fp32 kernel on the SAME bf16-rounded operands
+def _ulp_check(got_bf16, want_f32, what, max_ulps=1.01, floor_rms=0.0):
+    """`got` (bf16 tensor) must be the bf16 rounding of `want` (the fp32 kernel's result on the same operands) up to `max_ulps`
+    bf16 ulps per element (a value on a rounding boundary may go either way once the fp32 arithmetic differs in its last bit),
+    and the signed error must average out: a biased rounding (truncation instead of round-to-nearest-even, a dropped term)
+    shows as a mean error of a fraction of an ulp with one sign.  `floor_rms`: results that are differences of larger terms (the
+    batch-norm input gradient) carry the rounding of those terms, so their ulp is taken at no less than floor_rms x rms."""
+    got = got_bf16.detach().float().cpu().double(); want = want_f32.detach().cpu().double()
+    mag = want.abs().clamp_min(max(1e-30, floor_rms * want.pow(2).mean().sqrt().item()))
+    ulp = torch.pow(2.0, torch.floor(torch.log2(mag)) - 7)                                   # bf16: 8 significant bits
+    err = (got - want) / ulp
+    assert err.abs().max().item() <= max_ulps, '%s: %.2f bf16 ulps' % (what, err.abs().max().item())
+    assert abs(err.mean().item()) < 0.02, '%s: signed rounding error averages %.4f ulp (biased)' % (what, err.mean().item())
+
+
+def test_bf16_kernels_round_like_the_fp32_kernels_on_the_same_operands(pkg, dev):
+    """the end-to-end bf16 bounds are wide by nature, so each HBM-bound bf16 instantiation is held to the fp32
+    kernel on identical (bf16-representable) inputs: batch norm + swish forward and backward, batch norm + residual, depthwise
+    k3 / k5 forward and input gradient, squeeze (global average) and channel gating."""
+    ops, bf = pkg.ops, pkg.bf16
+    torch.manual_seed(17)
+    n, c, h, w = 4, 48, 40, 56
+    xb = (torch.randn(n, c, h, w) * 1.3 + 0.2).to(torch.bfloat16)
+    gb = torch.randn(n, c, h, w).to(torch.bfloat16)
+    rb = torch.randn(n, c, h, w).to(torch.bfloat16)
+
+    def bn_pair(act, res):
+        out = []
+        for kind in ('bf16', 'f32'):
+            bn = torch.nn.BatchNorm2d(c).to(dev).train()
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, c)); bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+            if kind == 'bf16':
+                x = bf.as_bf16(xb.to(dev)).requires_grad_(True); r = bf.as_bf16(rb.to(dev)).requires_grad_(True) if res else None
+                y = bf.batch_norm_act(x, bn, res=r, act=act)
+                y.backward(bf.as_bf16(gb.to(dev)))
+            else:
+                x = xb.float().to(dev).requires_grad_(True); r = rb.float().to(dev).requires_grad_(True) if res else None
+                y = ops.batch_norm_act(x, bn, res=r, act=act)
+                y.backward(gb.float().to(dev))
+            out.append((y, x.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_var.clone()))
+        return out
+    for act, res, tag in ((3, False, 'bn+swish'), (0, True, 'bn+res'), (0, False, 'bn')):
+        (yb, dxb, dwb, dbb, rvb), (yf, dxf, dwf, dbf, rvf) = bn_pair(act, res)
+        _ulp_check(yb, yf, tag + ' forward')
+        _ulp_check(dxb, dxf, tag + ' input gradient', max_ulps=1.6, floor_rms=1.0)   # dx = a*g - b - c*xhat: a difference of rms-sized terms
+        assert torch.allclose(dwb, dwf, rtol=2e-5, atol=2e-4) and torch.allclose(dbb, dbf, rtol=2e-5, atol=2e-4), tag + ' parameter gradients (fp32 / fp64 sums of the same values)'
+        assert torch.allclose(rvb, rvf, rtol=1e-6, atol=1e-7), tag + ' running variance'
+
+    for k in (3, 5):
+        wdw = (torch.randn(c, 1, k, k) / k).to(dev)
+        xq = bf.as_bf16(xb.to(dev)).requires_grad_(True)
+        yq = bf.dwconv2d(xq, wdw, 1, k // 2); yq.backward(bf.as_bf16(gb.to(dev)))
+        xf = xb.float().to(dev).requires_grad_(True)
+        yf = ops.dwconv2d(xf, wdw, None, 1, k // 2); yf.backward(gb.float().to(dev))
+        _ulp_check(yq, yf, 'depthwise k%d forward' % k)
+        _ulp_check(xq.grad, xf.grad, 'depthwise k%d input gradient' % k)
+
+    sqb = bf.global_avgpool(bf.as_bf16(xb.to(dev))); sqf = ops.global_avgpool(xb.float().to(dev))
+    assert torch.allclose(sqb, sqf, rtol=1e-6, atol=1e-7), 'squeeze: fp64 sums of the same values'
+    gate = torch.rand(n, c, 1, 1, device=dev)
+    _ulp_check(bf.channel_scale(bf.as_bf16(xb.to(dev)), gate), ops.channel_scale(xb.float().to(dev), gate), 'channel gate')
