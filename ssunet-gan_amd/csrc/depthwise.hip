@@ -155,7 +155,9 @@ struct DwS1Args {
 };
 constexpr int DW_XT = 4;
 
-template <int KW, typename T>
+// S = 2 (round 3): the same tiling for the stride-2 forward (the four stage transitions of an EfficientNet, 259 us each at B4 /
+// 1024^2 on the one-thread-per-output kernel): a thread's 4 outputs read (XT - 1) * 2 + KW source columns per kernel row.
+template <int KW, typename T, int S = 1>
 __global__ __launch_bounds__(256) void dw_s1_kernel(const DwS1Args<T> a) {
   extern __shared__ float w_s[];                         // [KH*KW][16][4]
   const int KK = a.KH * KW;
@@ -177,13 +179,14 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(const DwS1Args<T> a) {
 #pragma unroll
   for (int j = 0; j < DW_XT; ++j) acc[j] = b0;
   for (int ky = 0; ky < a.KH; ++ky) {
-    const int iy = oy + ky - a.pt;
+    const int iy = oy * S + ky - a.pt;
     if ((unsigned)iy >= (unsigned)a.SH) continue;
     const T* row = a.src + ((size_t)(n * a.SH + iy) * a.SW) * a.lds_ + 4 * cq;
-    f32x4 v[DW_XT + KW - 1];
+    constexpr int NV = (DW_XT - 1) * S + KW;
+    f32x4 v[NV];
 #pragma unroll
-    for (int j = 0; j < DW_XT + KW - 1; ++j) {
-      const int ix = x0 + j - a.pl;
+    for (int j = 0; j < NV; ++j) {
+      const int ix = x0 * S + j - a.pl;
       v[j] = (unsigned)ix < (unsigned)a.SW ? ld4(row + (size_t)ix * a.lds_) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float* wrow = w_s + (ky * KW) * 64 + tq * 4;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(const DwS1Args<T> a) {
     for (int kx = 0; kx < KW; ++kx) {
       const f32x4 wv = *(const f32x4*)(wrow + kx * 64);
 #pragma unroll
-      for (int j = 0; j < DW_XT; ++j) acc[j] += v[j + kx] * wv;
+      for (int j = 0; j < DW_XT; ++j) acc[j] += v[j * S + kx] * wv;
     }
   }
   T* orow = a.dst + ((size_t)(n * a.DH + oy) * a.DW_) * a.ldd + 4 * cq;
@@ -200,10 +203,89 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(const DwS1Args<T> a) {
     if (x0 + j < a.DW_) st4(orow + (size_t)(x0 + j) * a.ldd, acc[j]);
 }
 
-template <int KW, typename T>
+template <int KW, typename T, int S = 1>
 int launch_dw_s1(const DwS1Args<T>& a, hipStream_t st) {
   const dim3 grid((unsigned)((a.DW_ + 16 * DW_XT - 1) / (16 * DW_XT)), (unsigned)(a.N * a.DH), (unsigned)((a.C / 4 + 15) / 16));
-  hipLaunchKernelGGL((dw_s1_kernel<KW, T>), grid, dim3(256), (size_t)a.KH * KW * 64 * sizeof(float), st, a);
+  hipLaunchKernelGGL((dw_s1_kernel<KW, T, S>), grid, dim3(256), (size_t)a.KH * KW * 64 * sizeof(float), st, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+// stride-2 forward (k3 / k5: the shapes EfficientNet has); -1 = not covered
+template <typename T>
+int dw_s2_fwd_dispatch(const DwS1Args<T>& a, int KW, hipStream_t st) {
+  if ((long long)a.N * a.DH > 65535 || (a.C / 4 + 15) / 16 > 65535) return -1;
+  if (KW == 3) return launch_dw_s1<3, T, 2>(a, st);
+  if (KW == 5) return launch_dw_s1<5, T, 2>(a, st);
+  return -1;
+}
+
+// Stride-2 input gradient, same tiling: dx[y][x] = sum over (ky, kx) with (y + pt - ky) and (x + pl - kx) even of
+// dout[(y + pt - ky) / 2][(x + pl - kx) / 2] * w[ky][kx].  A thread owns 4 consecutive x of one channel quad; per kernel row of
+// matching parity it loads the <= 2 + (KW + 1) / 2 dout columns its outputs touch once and applies the taps whose parity fits
+// (x0 is a multiple of 4, so with the parity of pl as a template parameter every parity test and register index below is a
+// compile-time constant after unrolling).
+constexpr int floor_half(int t) { return (t - (t & 1)) / 2; }
+template <int KW, typename T, int PLODD>
+__global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const DwS1Args<T> a) {        // src = dout (SH x SW), dst = dx (DH x DW_)
+  extern __shared__ float w_s[];                         // [KH*KW][16][4]
+  const int KK = a.KH * KW;
+  const int tid = threadIdx.x, tq = tid & 15, xg = tid >> 4;
+  const int cq0 = blockIdx.z * 16;
+  for (int idx = tid; idx < KK * 64; idx += 256) {
+    const int t = idx >> 6, c = idx & 63;
+    const int ch = cq0 * 4 + c;
+    w_s[idx] = ch < a.C ? a.w[(size_t)ch * KK + t] : 0.f;
+  }
+  __syncthreads();
+  const int cq = cq0 + tq;
+  if (cq * 4 >= a.C) return;
+  const int y = blockIdx.y % a.DH, n = blockIdx.y / a.DH;
+  const int x0 = blockIdx.x * (16 * DW_XT) + xg * DW_XT;                      // multiple of 4
+  if (x0 >= a.DW_) return;
+  f32x4 acc[DW_XT];
+#pragma unroll
+  for (int j = 0; j < DW_XT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // dout columns touched: (x0 + j + pl - kx) / 2 for j in [0, 4), kx in [0, KW): from floor((x0 + pl - KW + 1) / 2) up
+  constexpr int NV = (DW_XT + KW) / 2 + 1;
+  const int base = (x0 + a.pl - (KW - 1) - ((x0 + a.pl - (KW - 1)) & 1)) / 2;  // floor of a possibly negative half
+  for (int ky = 0; ky < a.KH; ++ky) {
+    const int ty = y + a.pt - ky;
+    if (ty < 0 || (ty & 1)) continue;
+    const int oy = ty >> 1;
+    if (oy >= a.SH) continue;
+    const T* row = a.src + ((size_t)(n * a.SH + oy) * a.SW) * a.lds_ + 4 * cq;
+    f32x4 v[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int ox = base + q;
+      v[q] = (unsigned)ox < (unsigned)a.SW ? ld4(row + (size_t)ox * a.lds_) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* wrow = w_s + (ky * KW) * 64 + tq * 4;
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {
+      const f32x4 wv = *(const f32x4*)(wrow + kx * 64);
+#pragma unroll
+      for (int j = 0; j < DW_XT; ++j) {
+        // tx = x0 + j + pl - kx; with pl = 2m + PLODD and x0 % 4 == 0 its parity and its column relative to `base` are constants
+        const int e = j + PLODD - kx;
+        if ((e & 1) == 0) acc[j] += v[floor_half(e) - floor_half(PLODD - (KW - 1))] * wv;
+      }
+    }
+  }
+  T* orow = a.dst + ((size_t)(n * a.DH + y) * a.DW_) * a.ldd + 4 * cq;
+#pragma unroll
+  for (int j = 0; j < DW_XT; ++j)
+    if (x0 + j < a.DW_) st4(orow + (size_t)(x0 + j) * a.ldd, acc[j]);
+}
+template <typename T>
+int dw_s2_dgrad_dispatch(const DwS1Args<T>& a, int KW, hipStream_t st) {
+  if ((long long)a.N * a.DH > 65535 || (a.C / 4 + 15) / 16 > 65535) return -1;
+  const dim3 grid((unsigned)((a.DW_ + 16 * DW_XT - 1) / (16 * DW_XT)), (unsigned)(a.N * a.DH), (unsigned)((a.C / 4 + 15) / 16));
+  const size_t lds = (size_t)a.KH * KW * 64 * sizeof(float);
+  const bool odd = (a.pl & 1) != 0;
+  if (KW == 3) { if (odd) hipLaunchKernelGGL((dw_dgrad_s2_kernel<3, T, 1>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((dw_dgrad_s2_kernel<3, T, 0>), grid, dim3(256), lds, st, a); }
+  else if (KW == 5) { if (odd) hipLaunchKernelGGL((dw_dgrad_s2_kernel<5, T, 1>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((dw_dgrad_s2_kernel<5, T, 0>), grid, dim3(256), lds, st, a); }
+  else return -1;
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -240,13 +322,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs<T> a, lon
     for (long long p = p0 + pr; p < p1; p += PR) {
       const int ox = (int)(p % a.OW); const long long r = p / a.OW;
       const int oy = (int)(r % a.OH); const int n = (int)(r / a.OH);
-      const int iy = oy + ky - a.pt;
+      const int iy = oy * a.stride + ky - a.pt;          // stride 1, or 2 (round 3: the row-per-workgroup form for the stage transitions too)
       if ((unsigned)iy >= (unsigned)a.H) continue;
       const f32x4 g = ld4(a.dout + (size_t)p * a.ldo + 4 * cq);
       const T* row = a.in + ((size_t)(n * a.H + iy) * a.W) * a.ld + 4 * cq;
 #pragma unroll
       for (int kx = 0; kx < KW; ++kx) {
-        const int ix = ox + kx - a.pl;
+        const int ix = ox * a.stride + kx - a.pl;
         if ((unsigned)ix < (unsigned)a.W) {
           const f32x4 v = ld4(row + (size_t)ix * a.ld);
 #pragma unroll
@@ -430,6 +512,11 @@ int dwconv_fwd_impl(const T* in, int N, int H, int W, int C, int ld, const float
     rc = dw_s1_dispatch<T>(s1, KW, (hipStream_t)stream);
     if (rc >= 0) return rc;
   }
+  if (stride == 2 && KH == KW && ssg_aligned16(in) && ssg_aligned16(out)) {
+    const DwS1Args<T> s2{in, w, bias, out, N, H, W, OH, OW, C, ld, ldo, KH, pad_top, pad_left, 0};
+    rc = dw_s2_fwd_dispatch<T>(s2, KW, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   DwArgs<T> a{in, w, bias, nullptr, out, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, ldo};
   hipLaunchKernelGGL(dw_fwd_kernel<T>, dim3(elem_grid((long long)N * OH * OW * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
   SSG_LAUNCH_CHECK();
@@ -446,6 +533,11 @@ int dwconv_dgrad_impl(const T* dout, int lddo, int N, int H, int W, int C, const
     // dx = correlation of dout with the flipped kernel, pads K-1-pad
     const DwS1Args<T> s1{dout, w, nullptr, dx, N, OH, OW, H, W, C, lddo, lddx, KH, KH - 1 - pad_top, KW - 1 - pad_left, 1};
     rc = dw_s1_dispatch<T>(s1, KW, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
+  if (stride == 2 && KH == KW && ssg_aligned16(dout) && ssg_aligned16(dx)) {
+    const DwS1Args<T> s2{dout, w, nullptr, dx, N, OH, OW, H, W, C, lddo, lddx, KH, pad_top, pad_left, 0};
+    rc = dw_s2_dgrad_dispatch<T>(s2, KW, (hipStream_t)stream);
     if (rc >= 0) return rc;
   }
   DwArgs<T> a{nullptr, w, nullptr, dout, dx, N, H, W, C, lddx, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
@@ -466,7 +558,7 @@ int dwconv_wgrad_impl(const T* in, int N, int H, int W, int C, int ld, const T* 
   parts = (P + rpp - 1) / rpp;
   DwArgs<T> a{in, nullptr, nullptr, dout, nullptr, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
   hipStream_t st = (hipStream_t)stream;
-  if (stride == 1 && (KW == 3 || KW == 5 || KW == 7 || KW == 9)) {
+  if ((stride == 1 && (KW == 3 || KW == 5 || KW == 7 || KW == 9)) || (stride == 2 && (KW == 3 || KW == 5))) {
     if (KW == 3) launch_dw_wgrad_s1<3, T>(a, parts, rpp, (double*)ws, st);
     else if (KW == 5) launch_dw_wgrad_s1<5, T>(a, parts, rpp, (double*)ws, st);
     else if (KW == 7) launch_dw_wgrad_s1<7, T>(a, parts, rpp, (double*)ws, st);

@@ -310,7 +310,9 @@ def test_batch_norm_act(pkg, dev, shape, act, res):
     # n, c, h, w, k, stride, padding (int or (top, bottom, left, right))
     (2, 36, 19, 23, 3, 1, 1), (1, 64, 17, 70, 5, 1, 2), (2, 8, 21, 33, 7, 1, 3), (1, 72, 30, 45, 9, 1, 4),
     (2, 24, 16, 18, 3, 1, (0, 2, 0, 2)),            # asymmetric "static same" padding, stride 1
-    (2, 40, 17, 19, 5, 2, (1, 2, 1, 2)), (1, 16, 12, 14, 3, 2, 1),       # stride 2: the generic kernels
+    (2, 40, 17, 19, 5, 2, (1, 2, 1, 2)), (1, 16, 12, 14, 3, 2, 1),       # stride 2: the tiled stride-2 kernels (round 3), odd / even left pads
+    (2, 24, 32, 150, 3, 2, (0, 1, 0, 1)), (1, 72, 33, 131, 5, 2, (1, 2, 1, 2)), (2, 8, 20, 66, 5, 2, 2), (1, 20, 9, 70, 3, 2, (1, 1, 1, 1)),
+    (1, 12, 14, 16, 7, 2, 3),                                          # stride 2, k7: still the generic kernels
 ])
 def test_dwconv2d(pkg, dev, case):
     """Depthwise conv forward / input gradient / weight gradient (register-tiled stride-1 kernels and the generic ones)."""
