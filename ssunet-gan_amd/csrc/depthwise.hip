@@ -303,15 +303,19 @@ int dw_s1_dispatch(const DwS1Args<T>& a, int KW, hipStream_t st) {
 }
 
 // weight gradient, one kernel row ky per blockIdx.z: s[kx][e] += dout[p][c] * in[p + (ky, kx)][c]
-template <int KW, typename T>
+// Round 3: a thread takes FOUR consecutive output pixels of a row per iteration (4 dout quads + 3 S + KW input quads for
+// 16 KW multiply-adds per channel, where one pixel at a time cost 1 + KW loads for 4 KW): the kernel was bound by load issue
+// (PMC: 1.6 TB/s on `dw_wgrad_s1<5, bf16>`).  `rows_per_part` counts such x-quads.
+template <int KW, typename T, int S>
 __global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs<T> a, long long rows_per_part, double* __restrict__ part) {
   __shared__ double red[256][4];
   const int tid = threadIdx.x, tq = tid % DW_TQ, pr = tid / DW_TQ, PR = 256 / DW_TQ;
   const int CQ = a.C / 4, cq = blockIdx.y * DW_TQ + tq;
   const int ky = blockIdx.z;
-  const long long P = (long long)a.N * a.OH * a.OW;
-  const long long p0 = (long long)blockIdx.x * rows_per_part;
-  long long p1 = p0 + rows_per_part; if (p1 > P) p1 = P;
+  const int OW4 = (a.OW + 3) / 4;
+  const long long U = (long long)a.N * a.OH * OW4;
+  const long long u0 = (long long)blockIdx.x * rows_per_part;
+  long long u1 = u0 + rows_per_part; if (u1 > U) u1 = U;
   typedef typename SsgAcc<T>::type acc_t;
   acc_t s[KW][4];
 #pragma unroll
@@ -319,22 +323,30 @@ __global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs<T> a, lon
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[kx][e] = 0;
   if (cq < CQ) {
-    for (long long p = p0 + pr; p < p1; p += PR) {
-      const int ox = (int)(p % a.OW); const long long r = p / a.OW;
+    for (long long u = u0 + pr; u < u1; u += PR) {
+      const int xq = (int)(u % OW4); const long long r = u / OW4;
       const int oy = (int)(r % a.OH); const int n = (int)(r / a.OH);
-      const int iy = oy * a.stride + ky - a.pt;          // stride 1, or 2 (round 3: the row-per-workgroup form for the stage transitions too)
+      const int iy = oy * S + ky - a.pt;
       if ((unsigned)iy >= (unsigned)a.H) continue;
-      const f32x4 g = ld4(a.dout + (size_t)p * a.ldo + 4 * cq);
+      const int ox0 = xq * 4;
+      const T* grow = a.dout + ((size_t)(n * a.OH + oy) * a.OW) * a.ldo + 4 * cq;
+      f32x4 g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = ox0 + j < a.OW ? ld4(grow + (size_t)(ox0 + j) * a.ldo) : f32x4{0.f, 0.f, 0.f, 0.f};
       const T* row = a.in + ((size_t)(n * a.H + iy) * a.W) * a.ld + 4 * cq;
+      constexpr int NV = 3 * S + KW;
+      f32x4 v[NV];
 #pragma unroll
-      for (int kx = 0; kx < KW; ++kx) {
-        const int ix = ox * a.stride + kx - a.pl;
-        if ((unsigned)ix < (unsigned)a.W) {
-          const f32x4 v = ld4(row + (size_t)ix * a.ld);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s[kx][e] += (acc_t)g[e] * (acc_t)v[e];
-        }
+      for (int q = 0; q < NV; ++q) {
+        const int ix = ox0 * S + q - a.pl;
+        v[q] = (unsigned)ix < (unsigned)a.W ? ld4(row + (size_t)ix * a.ld) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[kx][e] += (acc_t)g[j][e] * (acc_t)v[j * S + kx][e];
     }
   }
   for (int kx = 0; kx < KW; ++kx) {
@@ -353,9 +365,14 @@ __global__ __launch_bounds__(256) void dw_wgrad_s1_kernel(const DwArgs<T> a, lon
     }
   }
 }
+// (All K x K taps in one workgroup -- K*K*4 accumulators per thread, dout and the input read once instead of K times -- was built
+//  and measured in round 3: B4 bf16 137.6 -> 124.0 images/s, fp32 94.2 -> 90.8: 222-256 registers and a K*K-round reduction
+//  epilogue cost more than the K-fold re-read, which the L2 serves.)
 template <int KW, typename T>
 void launch_dw_wgrad_s1(const DwArgs<T>& a, long long parts, long long rpp, double* ws, hipStream_t st) {
-  hipLaunchKernelGGL((dw_wgrad_s1_kernel<KW, T>), dim3((unsigned)parts, (unsigned)((a.C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)a.KH), dim3(256), 0, st, a, rpp, ws);
+  const dim3 grid((unsigned)parts, (unsigned)((a.C / 4 + DW_TQ - 1) / DW_TQ), (unsigned)a.KH);
+  if (a.stride == 2) hipLaunchKernelGGL((dw_wgrad_s1_kernel<KW, T, 2>), grid, dim3(256), 0, st, a, rpp, ws);
+  else hipLaunchKernelGGL((dw_wgrad_s1_kernel<KW, T, 1>), grid, dim3(256), 0, st, a, rpp, ws);
 }
 
 // ---------------------------------------------------------------- unary ops (fwd / bwd)
@@ -552,13 +569,16 @@ int dwconv_wgrad_impl(const T* in, int N, int H, int W, int C, int ld, const T* 
   int rc = dw_check("dwconv_wgrad", in, N, H, W, C, ld, KH, KW, stride);
   if (rc) return rc;
   SSG_REQUIRE(dout && dw && ws && OH > 0 && OW > 0, SSG_EINVAL, "dwconv_wgrad: bad args");
-  const long long P = (long long)N * OH * OW;
+  const bool tiled = (stride == 1 && (KW == 3 || KW == 5 || KW == 7 || KW == 9)) || (stride == 2 && (KW == 3 || KW == 5));
+  // work units: pixels, or x-quads of 4 consecutive output pixels for the tiled kernels; the partial buffer is sized for the
+  // pixel count (ssg_dwconv2d_wgrad_workspace_bytes), which bounds both
+  const long long P = tiled ? (long long)N * OH * ((OW + 3) / 4) : (long long)N * OH * OW;
   long long parts = (P + 255) / 256; if (parts > 256) parts = 256; if (parts < 1) parts = 1;
   const long long rpp = (P + parts - 1) / parts;
   parts = (P + rpp - 1) / rpp;
   DwArgs<T> a{in, nullptr, nullptr, dout, nullptr, N, H, W, C, ld, KH, KW, stride, pad_top, pad_left, OH, OW, lddo};
   hipStream_t st = (hipStream_t)stream;
-  if ((stride == 1 && (KW == 3 || KW == 5 || KW == 7 || KW == 9)) || (stride == 2 && (KW == 3 || KW == 5))) {
+  if (tiled) {
     if (KW == 3) launch_dw_wgrad_s1<3, T>(a, parts, rpp, (double*)ws, st);
     else if (KW == 5) launch_dw_wgrad_s1<5, T>(a, parts, rpp, (double*)ws, st);
     else if (KW == 7) launch_dw_wgrad_s1<7, T>(a, parts, rpp, (double*)ws, st);
