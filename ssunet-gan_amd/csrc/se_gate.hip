@@ -16,7 +16,7 @@ constexpr int SE_MAXN = 16;
 // threads with a wave butterfly per (n, s): 53-60 us, shuffle-bound.)
 constexpr int SE_CK = 64;
 
-// sum_k part[k][i] in a fixed order, eight loads in flight
+// sum_k part[k][i] in a fixed order, eight loads in flight (a 16-wide guarded form was slower: 18 -> 21 us per consumer launch)
 __device__ __forceinline__ float sum_parts(const float* __restrict__ part, int nck, int NS, int i) {
   float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int k = 0;
@@ -83,15 +83,22 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
 #pragma unroll
   for (int n = 0; n < SE_MAXN; ++n) acc[n] = bv;
   const float* wr = w2 + (size_t)c * S;
-  if ((S & 3) == 0) {                                    // rows are 16-byte aligned: a quarter of the (per-thread-row) load instructions
-#pragma unroll 2
-    for (int s = 0; s < S; s += 4) {
-      const f32x4 wv = *(const f32x4*)(wr + s);
+  if ((S & 3) == 0) {
+    // rows are 16-byte aligned; 16 row quads (64 squeezed channels) are requested together, so a row of S = 112 costs two
+    // round trips instead of one per quad pair (the loop was a chain of load latencies: 16.5 us per launch)
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      f32x4 wv[16];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int q = 0; q < 16; ++q) wv[q] = s0 + 4 * q < S ? *(const f32x4*)(wr + s0 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < SE_MAXN; ++n)
-          if (n < N) acc[n] = fmaf(wv[e], hs[n * S + s + e], acc[n]);
+      for (int q = 0; q < 16; ++q)
+        if (s0 + 4 * q < S) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int n = 0; n < SE_MAXN; ++n)
+              if (n < N) acc[n] = fmaf(wv[q][e], hs[n * S + s0 + 4 * q + e], acc[n]);
+        }
     }
   } else {
 #pragma unroll 4
@@ -170,17 +177,22 @@ __global__ __launch_bounds__(256) void se_bwd_in_kernel(const float* __restrict_
     }
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  float q[SE_MAXN], acc[SE_MAXN];
+  float q_[SE_MAXN], acc[SE_MAXN];
 #pragma unroll
-  for (int n = 0; n < SE_MAXN; ++n) { q[n] = n < N ? sq[(size_t)n * ldq + c] : 0.f; acc[n] = 0.f; }
-#pragma unroll 8
-  for (int s = 0; s < S; ++s) {
-    const float wv = w1[(size_t)s * C + c];
-    float t = 0.f;
+  for (int n = 0; n < SE_MAXN; ++n) { q_[n] = n < N ? sq[(size_t)n * ldq + c] : 0.f; acc[n] = 0.f; }
+  for (int s0 = 0; s0 < S; s0 += 16) {                   // 16 (coalesced) weight loads in flight, then 16 stores
+    float wv[16];
 #pragma unroll
-    for (int n = 0; n < SE_MAXN; ++n)
-      if (n < N) { const float dh = hs[n * S + s]; t = fmaf(dh, q[n], t); acc[n] = fmaf(wv, dh, acc[n]); }
-    dw1[(size_t)s * C + c] = t;
+    for (int q = 0; q < 16; ++q) wv[q] = s0 + q < S ? w1[(size_t)(s0 + q) * C + c] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (s0 + q < S) {
+        float t = 0.f;
+#pragma unroll
+        for (int n = 0; n < SE_MAXN; ++n)
+          if (n < N) { const float dh = hs[n * S + s0 + q]; t = fmaf(dh, q_[n], t); acc[n] = fmaf(wv[q], dh, acc[n]); }
+        dw1[(size_t)(s0 + q) * C + c] = t;
+      }
   }
 #pragma unroll
   for (int n = 0; n < SE_MAXN; ++n)
