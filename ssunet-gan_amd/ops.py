@@ -489,6 +489,7 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, stride, pad, act, slope, res=None, want_bn=False):
+        ctx.set_materialize_grads(False)       # no zero tensor for the (non-differentiable) statistics output's gradient
         x1 = to_nhwc(x1)
         x2 = to_nhwc(x2) if x2 is not None else None
         res = to_nhwc(res) if res is not None else None
@@ -506,6 +507,8 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy, _=None):
+        if dy is None:
+            return (None,) * 10
         x1, x2, weight, y = ctx.saved_tensors
         stride, pad, act, slope = ctx.cfg
         dy = to_nhwc(dy)
