@@ -466,6 +466,10 @@ def main():
             line['grad_bucket_allreduce'] = buckets
         if world == 1:
             line['measured_ceilings'] = measured_ceilings(S, dev)
+            # the split kernels against what the bf16 pipe of THIS device sustains on random operands (power-limited: DESIGN.md 3.9)
+            if roof and roof.get('executed') and line['measured_ceilings'].get('mfma_bf16_random_operand_tflops'):
+                roof['executed']['frac_of_measured_random_operand_rate'] = round(
+                    roof['executed']['achieved'] / line['measured_ceilings']['mfma_bf16_random_operand_tflops'], 4)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
