@@ -93,8 +93,14 @@ typedef struct {
  * out, results agree with the fp32-MFMA kernel to fp32 accumulation accuracy (tests/test_split_gpu.py), at 16/6 of its
  * matrix rate.  ssg_conv2d_split_bn: 0 when the launch for `d` has no split-operand kernel, else the column tile (64 / 128)
  * its weights must be split for: `w_split` = ssg_pack_weights_split_bf16x3(d->w rows [R][Kp] in kmode 0, R, Kp, BN) --
- * ssg_pack_weights_split_bytes bytes, layout [ceil(R/BN)][Kp/16][BN][96 B]. */
+ * ssg_pack_weights_split_bytes bytes, layout [ceil(R/BN)][Kp/16][BN][96 B].
+ * ABI 7 (round 4): ssg_conv2d_split_bn may also return 1128 or 1064 -- the launch goes to the 32-channel-chunk kernel on
+ * v_mfma_f32_16x16x32_bf16 (conv_igemm_halo_k32.hip: 8 x 32-pixel x 128-channel tiles of 512 threads, or 4 x 32 x 64 of 256), whose
+ * weights are packed by the same two functions with BN = that code: layout [R/bn][Kp/32 steps = chunk32 * 9 + tap][bn/16
+ * fragments][3 planes][64 lanes][16 B] (bn = code - 1000; R % bn == 0, Kp % 288 == 0).  ssg_conv_set_k32_mode(0 / 1 / 2): never /
+ * where the grid fills the chip (default, SSG_K32) / wherever the shape is legal (tests); returns the previous mode. */
 int ssg_conv2d_split_bn(const ssg_conv_desc* d);
+int ssg_conv_set_k32_mode(int mode);
 int64_t ssg_pack_weights_split_bytes(int R, int Kp, int BN);
 int ssg_pack_weights_split_bf16x3(const float* w_packed, int R, int Kp, int BN, void* out, void* stream);
 
@@ -431,7 +437,9 @@ int ssg_spectral_norm_bwd_f32(const float* dWsn, const float* W, int rows, int c
  * h_pre ([N][S], dense) is kept for the backward.  Range: N <= 16, S <= 256, N*S <= 2048 (ssg_se_gate_ok; outside it the
  * caller keeps the conv path).  Backward: from dgate it writes dsq [N][C] (stride lds_), dw1 [S][C], db1 [S] (may be NULL),
  * dw2 [C][S], db2 [C] (may be NULL).  tmp = ssg_se_gate_workspace_floats(N, C, S) floats of scratch in either direction
- * (partial sums per 64-channel chunk; dz in the backward).  All sums run in a fixed order. */
+ * (partial sums per 64-channel chunk; dz in the backward; the entry points cannot check its size).  All sums run in a fixed
+ * order.  Alignment: when S % 4 == 0 the rows of w2 (and dw2 in the backward) are accessed 16 bytes at a time, so w2 / dw2 must
+ * be 16-byte aligned (SSG_EALIGN otherwise) -- a view at an odd offset inside a flat parameter buffer is refused, not mis-read. */
 int ssg_se_gate_ok(int N, int C, int S);
 int64_t ssg_se_gate_workspace_floats(int N, int C, int S);
 int ssg_se_gate_fwd_f32(const float* sq, int ldq, int N, int C, const float* w1, const float* b1, const float* w2, const float* b2,

@@ -34,7 +34,17 @@ class ActivationPattern(object):
         self.mode, self.items, self.pos = mode, (items if items is not None else []), 0
         # impose + keep: `seen` receives, in call order, the pre-activation (act) / pool input this run computed at each decision
         # while it FOLLOWED the imposed pattern up to there -- so a decision can be checked given identical upstream decisions
+        # keep may also be a callable(k, x, item): the value is handed over as it is computed and nothing is retained (the
+        # 16 x 512^2 forward has 2.2e9 decisions: 9 GB of pre-activations if they were all kept)
         self.keep, self.seen = keep, []
+
+    def note(self, x):
+        k = self.pos - 1
+        if callable(self.keep):
+            self.keep(k, x.detach(), self.items[k])
+            self.seen.append(None)
+        else:
+            self.seen.append(x.detach().clone())
 
 
 PATTERN = None
@@ -49,7 +59,7 @@ def _act(x, slope=0.0):
     m = P.items[P.pos]; P.pos += 1
     assert m.shape == x.shape, 'activation pattern out of step: %s vs %s' % (tuple(m.shape), tuple(x.shape))
     if P.keep:
-        P.seen.append(x.detach().clone())
+        P.note(x)
     return torch.where(m, x, x * slope)
 
 
@@ -79,7 +89,7 @@ class _MaxPoolIdx(nn.Module):
             return y, idx
         win = P.items[P.pos]; P.pos += 1
         if P.keep:
-            P.seen.append(x.detach().clone())
+            P.note(x)
         n, c, h, w = x.shape
         assert win.shape == (n, c, h // 2, w // 2)
         xs = x.unfold(2, 2, 2).unfold(3, 2, 2).reshape(n, c, h // 2, w // 2, 4)

@@ -76,6 +76,7 @@ SIGNATURES = {
     'ssg_conv2d_workspace_bytes': [C.POINTER(ConvDesc)],
     'ssg_conv2d_split_bn': [C.POINTER(ConvDesc)],
     'ssg_pack_weights_split_bytes': [_I, _I, _I],
+    'ssg_conv_set_k32_mode': [_I],
     'ssg_pack_weights_split_bf16x3': [_P, _I, _I, _I, _P, _P],
     'ssg_bn_stats_from_partials_workspace_bytes': [_I, _I],
     'ssg_bn_stats_from_partials_f32': [_P, _I, _I, _P, _D, _P, _P],
@@ -182,7 +183,7 @@ _RESTYPES = {
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_split_bn', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
                                 'ssg_spade_conv_modulate_ok', 'ssg_se_gate_ok'}
 
-ABI_VERSION = 6          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
+ABI_VERSION = 7          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
 
 _lib = None
 

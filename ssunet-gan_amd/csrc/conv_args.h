@@ -39,6 +39,11 @@ int ssg_conv_halo_x3_bn(const ConvArgs& a, int variant);      // column tile (64
 int ssg_conv_igemm_halo_x3_launch(const ConvArgs& a, int variant, hipStream_t st);
 bool ssg_conv_halo_x3_parity_ok(const ConvArgs& a);          // the four parity classes of a 3x3 stride-2 input gradient as one launch
 int ssg_conv_igemm_halo_x3_parity_launch(const ConvArgs& a, hipStream_t st);
+// conv_igemm_halo_k32.hip (round 4): 32-channel chunks on v_mfma_f32_16x16x32_bf16; split-pack format code 1128 / 1064, or 0
+int ssg_conv_halo_k32_fmt(const ConvArgs& a);
+void ssg_conv_halo_k32_tile(int fmt, int* th, int* tw);
+int ssg_conv_igemm_halo_k32_launch(const ConvArgs& a, int fmt, hipStream_t st);
+int ssg_pack_split_k32_launch(const float* w_packed, int R, int Kp, int BN, void* out, hipStream_t st);
 // conv_igemm_dma_x3.hip: the LDS-DMA pipeline (1x1, stride 2, parity classes) with split operands; column tile 128 / 64 or 0 = not eligible
 int ssg_conv_dma_x3_bn(const ConvArgs& a);
 int ssg_conv_igemm_dma_x3_launch(const ConvArgs& a, hipStream_t st);

@@ -295,7 +295,7 @@ ConvArgs to_args(const ssg_conv_desc* d) {
   return a;
 }
 
-// column tile of the split-operand kernel for `d`, or 0: 3x3 unit-stride launches on the halo path that would not split K
+// column tile (64 / 128; 1064 / 1128 = the k32 pack format of conv_igemm_halo_k32.hip) of the split-operand kernel for `d`, or 0: 3x3 unit-stride launches on the halo path that would not split K
 int split_bn(const ssg_conv_desc* d) {
   if (!uses_dma(d) || d->Cout <= 32) return 0;
   const ConvArgs a = to_args(d);
@@ -303,6 +303,8 @@ int split_bn(const ssg_conv_desc* d) {
   if (!uses_halo(a)) return ssg_conv_dma_x3_bn(a);            // 1x1, stride 2, parity-class launches: the LDS-DMA pipeline
   if (!ssg_conv_halo_x3_ok(a, pick_variant(d))) return 0;
   if (d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) && ssg_conv_halo_ksplit(a, pick_variant(d)) > 1) return 0;   // small grids keep split-K
+  const int k32 = ssg_conv_halo_k32_fmt(a);                     // 1128 / 1064: the 32-channel-chunk kernel and its pack format
+  if (k32) return k32;
   return ssg_conv_halo_x3_bn(a, pick_variant(d));
 }
 
@@ -317,7 +319,8 @@ extern "C" int ssg_conv2d_bnpart_rows(const ssg_conv_desc* d) {
   const ConvArgs a = to_args(d);
   int th, tw;
   if (d->w_split && split_bn(d) > 0) {                          // split-operand kernels: 4 x 32-pixel halo tiles (also where fp32 takes <256,64>), 8 x 16 DMA tiles
-    if (uses_halo(a)) { th = 4; tw = 32; } else { th = 8; tw = 16; }
+    if (split_bn(d) >= 1000) ssg_conv_halo_k32_tile(split_bn(d), &th, &tw);
+    else if (uses_halo(a)) { th = 4; tw = 32; } else { th = 8; tw = 16; }
   }
   else if (uses_halo(a)) {
     if (d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) && ssg_conv_halo_ksplit(a, pick_variant(d)) > 1) return 0;   // split-K launch: no statistics epilogue
@@ -368,6 +371,7 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
       a.w = (const float*)d->w_split; a.ws = nullptr; a.ksplit = 1;
       if (d->parity_merge) return ssg_conv_igemm_halo_x3_parity_launch(a, st);
       if (!uses_halo(a)) return ssg_conv_igemm_dma_x3_launch(a, st);
+      if (split_bn(d) >= 1000) return ssg_conv_igemm_halo_k32_launch(a, split_bn(d), st);
       return ssg_conv_igemm_halo_x3_launch(a, pick_variant(d), st);
     }
     if (uses_halo(a)) return ssg_conv_igemm_halo_launch(a, pick_variant(d), st);

@@ -1,0 +1,379 @@
+// 3x3 stride-1 convolution (forward and input gradient), split-operand form on v_mfma_f32_16x16x32_bf16 with 32-channel chunks
+// (round 4).  Same contract as conv_igemm_halo_x3.hip (fp32 tensors in HBM, every operand x = x1 + x2 + x3 in bf16 terms, six
+// products, fp32 accumulation: mfma_split.h), different machine mapping -- chosen from measurements of loop skeletons on random
+// operands (tools/mfma_lab.hip):
+//   * the bf16 pipe is power-limited, and the 16x16x32 shape delivers 1.15x the FLOP/s of 32x32x16 at the clock the chip then
+//     holds (bare loops: 2.00 vs 1.73 PFLOP/s); inside a ring skeleton the same change is worth +9 %;
+//   * a 512-thread workgroup on a 256-pixel x 128-channel tile (8 waves = 4 x 2, each 64 pixels x 64 channels) streams HALF the
+//     weight bytes per FLOP of the 128 x 128 tile through LDS and fetches 1.33x instead of 1.59x the pixels (halo overhead);
+//     skeleton 1.67 PFLOP/s executed against 1.34 for the 256-thread 128 x 64 form;
+//   * one K-step = one tap x 32 channels: 96 MFMAs per wave between two workgroup barriers (24 in the x3 kernel), and a 128-byte
+//     line of the NHWC input is fetched once (the 16-channel chunks of the x3 kernel fetched it twice, 9 steps apart).
+// Data flow per workgroup:
+//   weights  [Cout tile][step = chunk32 * 9 + tap][fragment j][plane][lane][16 B]  (ssg_pack_weights_split_bf16x3, fmt 1128 / 1064)
+//            -> ring of 3 stages x BN*192 B by LDS-DMA, lane-linear 1-KiB pieces: a fragment read is base + lane * 16, conflict-free;
+//            the weights are the A operand (rows = output channels), so a lane ends up with 4 consecutive output channels of one
+//            pixel and stores them as one 16-byte access;
+//   pixels   fp32 NHWC -> registers (buffer loads, 32 B per lane: 8 channels of one halo pixel; out-of-image lanes read zeros
+//            through the descriptor's range check) -> split3 -> LDS image [plane][k-group][NPIX][16 B] (single-buffered: the
+//            loads for chunk c+1 are issued at tap 4 of chunk c, split at tap 8, written between two barriers at the chunk
+//            boundary).  A pixel fragment of any tap is 16 consecutive pixels of one k-group row: with NPIX % 16 == 0 the
+//            ds_read_b128 lane groups hit 16 distinct 16-byte bank slots at every alignment.
+// LDS: 66 KB image + 72 KB ring = 138 KB (one workgroup per CU) for <8 rows, 128 ch>; 39 + 36 = 75 KB (two per CU) for <4 rows, 64 ch>.
+#include "common.h"
+#include "lds_dma.h"
+#include "conv_args.h"
+#include "mfma_split.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int TH, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 1 : 2) void conv_halo_k32_kernel(const ConvArgs a) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int TW = 32, BM = TH * TW;
+  constexpr int HW = TW + 2, HR = (TH + 2) * HW;
+  constexpr int NPIX = (HR + 15) / 16 * 16;
+  constexpr int PLANE = 4 * NPIX * 16;                   // bytes of one plane of the pixel image
+  constexpr int IMG = 3 * PLANE;
+  constexpr int BSTG = BN * 192;                         // bytes of one weight stage (one tap x 32 channels x 3 planes)
+  constexpr int BPIECES = BSTG / 1024;
+  constexpr int B_PC = BPIECES / NW;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MI = WTM / 16, NI = WTN / 16;
+  constexpr int NBLK = (HR + 63) / 64, ITEMS = NBLK * 4, IPW = ITEMS / NW, NLD = 2 * IPW;
+  constexpr int LD_T = 4;                                // tap step at which the next chunk's pixel loads are issued
+  static_assert(BPIECES % NW == 0 && ITEMS % NW == 0, "uniform DMA pieces / load items per wave");
+  static_assert(IMG % 1024 == 0, "the ring behind the image stays 1-KiB aligned");
+  static_assert(WTM == 64, "a wave owns two 32-pixel tile rows");
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  unsigned char* const img = lds;
+  unsigned char* const ring = lds + IMG;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l15 = lane & 15, kg = lane >> 4;
+
+  int bid = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int per = (int)gridDim.x >> 3;
+    if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int nyt = a.ntiles_n;
+  const int nt = bid % nyt; bid /= nyt;
+  const int n0 = nt * BN;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int n = bid / a.tiles_y;
+
+  const int nchunks = (a.C1 + a.C2) >> 5;
+  const int nsteps = nchunks * 9;
+  const unsigned OOB = 0xffffffffu;
+  const unsigned npix = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W;
+  const auto in1_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in1), 0, (int)(npix * (unsigned)a.ld1 * 4u), 0x00020000);
+  const auto in2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in2), 0, (int)(npix * (unsigned)a.ld2 * 4u), 0x00020000);
+  const auto w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)((unsigned)nyt * (unsigned)nsteps * (unsigned)BSTG), 0x00020000);
+  const unsigned w_tile = (unsigned)nt * (unsigned)nsteps * (unsigned)BSTG;
+
+  // ---- pixel load items of this thread: item (wave * IPW + k) = (64-pixel block of the halo, k-group); lane = pixel of the block
+  unsigned px_pix[IPW];                                  // pixel index in the input tensor, or OOB
+  int px_dst[IPW];                                       // byte offset in a plane of the image, or -1 (lane beyond the halo)
+  unsigned px_kg[IPW];
+#pragma unroll
+  for (int k = 0; k < IPW; ++k) {
+    const int it = wave * IPW + k;
+    const int blk = it >> 2, g = it & 3;
+    const int hp = blk * 64 + lane;
+    const int hy = hp / HW, hx = hp - hy * HW;
+    const int iy = ty * TH + hy - 1, ix = tx * TW + hx - 1;
+    const bool in_halo = hp < HR;
+    const bool ok = in_halo && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    px_pix[k] = ok ? (unsigned)((n * a.H + iy) * a.W + ix) : OOB;
+    px_dst[k] = in_halo ? (g * NPIX + hp) * 16 : -1;
+    px_kg[k] = (unsigned)g * 32u;
+  }
+  u32x4 raw[NLD];
+  auto load_px = [&](int chunk) {
+    const int c0 = chunk * 32;
+    const bool live = chunk < nchunks;                   // past the last chunk: out-of-range lanes keep vmcnt uniform, nothing is fetched
+    const bool first = c0 < a.C1;
+    const unsigned ld4 = (unsigned)(first ? a.ld1 : a.ld2) * 4u;
+    const unsigned so = (unsigned)(first ? c0 : c0 - a.C1) * 4u;
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+      const unsigned vo = (live && px_pix[k] != OOB) ? px_pix[k] * ld4 + px_kg[k] : OOB;
+      const unsigned vo2 = (live && px_pix[k] != OOB) ? vo + 16u : OOB;
+      if (first) {
+        raw[2 * k] = __builtin_amdgcn_raw_buffer_load_b128(in1_rs, vo, so, 0);
+        raw[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(in1_rs, vo2, so, 0);
+      } else {
+        raw[2 * k] = __builtin_amdgcn_raw_buffer_load_b128(in2_rs, vo, so, 0);
+        raw[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(in2_rs, vo2, so, 0);
+      }
+    }
+  };
+  bf16x8 cv[IPW][3];
+  auto convert_px = [&]() {
+#pragma unroll
+    for (int k = 0; k < IPW; ++k)
+      split3(__builtin_bit_cast(f32x4, raw[2 * k]), __builtin_bit_cast(f32x4, raw[2 * k + 1]), cv[k][0], cv[k][1], cv[k][2]);
+  };
+  auto write_px = [&]() {
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+      if (px_dst[k] >= 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *(bf16x8*)(img + q * PLANE + px_dst[k]) = cv[k][q];
+      }
+    }
+  };
+  auto issue_b = [&](int s) {
+    unsigned char* st = ring + (s % 3) * BSTG;
+    // past the last step the pieces are dummies that keep vmcnt uniform: they re-read step 0
+    const unsigned so = w_tile + (s < nsteps ? (unsigned)s * (unsigned)BSTG : 0u);
+#pragma unroll
+    for (int j = 0; j < B_PC; ++j) {
+      const int g = wave + NW * j;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (ssg_lds_void*)(st + g * 1024), 16, (unsigned)lane * 16u, so + g * 1024, 0, 0);
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int pb[MI];                                            // byte offset of this lane's pixel in a plane of the image, tap (0, 0)
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int p = wm * WTM + i * 16 + l15;
+    pb[i] = (kg * NPIX + ((p >> 5) + 1) * HW + (p & 31) + 1) * 16;
+  }
+  const int wfrag = wn * NI * 3 * 1024 + lane * 16;      // this lane's 16 bytes of fragment (wn * NI + j), plane q: + (j * 3 + q) * 1024
+
+  // ---- prologue: pixels of chunk 0 (loads first: they are the oldest vmcnt entries), two weight steps in flight
+  load_px(0);
+  issue_b(0);
+  issue_b(1);
+  wait_vmcnt<2 * B_PC>();
+  convert_px();
+  write_px();
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int s = chunk * 9 + t;
+      if (t == LD_T + 1 || t == LD_T + 2) wait_vmcnt<B_PC + NLD>();      // the pixel loads issued at LD_T may still be in flight
+      else wait_vmcnt<B_PC>();
+      wait_lds_reads();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t == 0 && chunk > 0) {
+        // every wave has left the last tap of the previous chunk: replace the image
+        write_px();
+        wait_lds_reads();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      issue_b(s + 2);
+      if (t == LD_T) load_px(chunk + 1);
+
+      const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
+      const int toff = (((tb & 7) - 2) * HW + ((tb >> 3) - 2)) * 16;
+      const unsigned char* st = ring + (t % 3) * BSTG + wfrag;            // s % 3 == t % 3 (9 steps per chunk)
+      bf16x8 p[MI][3], w[NI][3];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) p[i][q] = *(const bf16x8*)(img + q * PLANE + pb[i] + toff);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) w[j][q] = *(const bf16x8*)(st + (j * 3 + q) * 1024);
+      // small terms first
+#define SSG_K32_TERM(QW, QP)                                                                      \
+  _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                  \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                  \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][QW], p[i][QP], acc[i][j], 0, 0, 0);
+      SSG_K32_TERM(2, 0) SSG_K32_TERM(1, 1) SSG_K32_TERM(0, 2)
+      SSG_K32_TERM(1, 0) SSG_K32_TERM(0, 1)
+      SSG_K32_TERM(0, 0)
+#undef SSG_K32_TERM
+      if (t == 8) convert_px();                          // the loads of LD_T landed before tap 7's barrier; VALU work beside the MFMAs
+    }
+  }
+  wait_vmcnt<0>();
+  wait_lds_reads();
+
+  // ---- epilogue.  acc[i][j][r]: pixel p = wm*64 + i*16 + l15, output channel n0 + wn*WTN + j*16 + kg*4 + r.
+  const bool want_bn = a.bnpart != nullptr;
+  if (want_bn) __syncthreads();                          // the image and the ring are dead for every wave: LDS becomes scratch
+  double* const red = (double*)lds;                      // [WAVES_M][2][BN]
+  size_t opix[MI]; bool pok[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int p = wm * WTM + i * 16 + l15;
+    const int gy = ty * TH + (p >> 5), gx = tx * TW + (p & 31);
+    pok[i] = gy < a.GH && gx < a.GW;
+    opix[i] = (size_t)(n * a.OH + gy * a.out_sy + a.out_oy) * a.OW + gx * a.out_sx + a.out_ox;
+  }
+  float nvl = 0.f;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) nvl += pok[i] ? 1.f : 0.f;
+  if (want_bn) {
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) nvl += __shfl_xor(nvl, m, 64);       // valid pixels of this wave's 16-lane row group
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn * WTN + j * 16 + kg * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = *(const f32x4*)(a.bias + co);
+    if (want_bn) {
+      // Column sums for the batch-norm statistics: fp32 sums of DEVIATIONS from a pivot shared by the 16 lanes of a row group (the
+      // group's first value of the column), converted to sums of the values in fp64 once per wave and column:
+      // S1 = s1 + n*c, S2 = s2 + 2*c*s1 + n*c^2 (plain fp32 sums of v and v^2 lose var = E[v^2] - mean^2 once |mean| >> std).
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float piv = __shfl(acc[0][j][r] + bv[r], lane & 48, 64);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const float dv = pok[i] ? (acc[i][j][r] + bv[r]) - piv : 0.f;
+          s1 += dv; s2 += dv * dv;
+        }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+        if (l15 == 0) {
+          const double c = (double)piv, nn = (double)nvl;
+          const int col = wn * WTN + j * 16 + kg * 4 + r;
+          red[(wm * 2 + 0) * BN + col] = (double)s1 + nn * c;
+          red[(wm * 2 + 1) * BN + col] = (double)s2 + 2.0 * c * (double)s1 + nn * c * c;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (!pok[i]) continue;
+      f32x4 v = acc[i][j] + bv;
+      if (a.res) v += *(const f32x4*)(a.res + opix[i] * a.ldr + co);
+      if (a.act == SSG_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
+      } else if (a.act == SSG_ACT_LRELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
+      }
+      *(f32x4*)(a.out + opix[i] * a.ldo + co) = v;
+    }
+  }
+  if (want_bn) {
+    __syncthreads();
+    if (tid < BN) {
+      double t1 = 0, t2 = 0;
+#pragma unroll
+      for (int k = 0; k < WAVES_M; ++k) { t1 += red[(k * 2 + 0) * BN + tid]; t2 += red[(k * 2 + 1) * BN + tid]; }
+      double* dst = a.bnpart + (size_t)((n * a.tiles_y + ty) * a.tiles_x + tx) * 2 * a.Cout;
+      dst[n0 + tid] = t1; dst[a.Cout + n0 + tid] = t2;
+    }
+  }
+}
+
+// fp32 packed [R][Kp] (kmode 0 with 9 taps: k = (chunk16 * 9 + tap) * 16 + c) -> [R / BN][chunk32 * 9 + tap][BN / 16 fragments][3 planes][64 lanes][16 B]:
+// lane l of fragment j holds output channel j*16 + (l & 15), channels chunk32*32 + (l >> 4)*8 .. +7.  One thread per (row, step, k-group).
+__global__ __launch_bounds__(256) void pack_split_k32_kernel(const float* __restrict__ w, int R, int Kp, int BN, unsigned char* __restrict__ out) {
+  const int nsteps = Kp >> 5;                            // 32-channel steps
+  const long long total = (long long)(R / BN) * BN * nsteps * 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int g = (int)(i & 3);
+    long long t = i >> 2;
+    const int s = (int)(t % nsteps); t /= nsteps;
+    const int row = (int)t;
+    const int tile = row / BN, rl = row - tile * BN;
+    const int chunk32 = s / 9, tap = s - chunk32 * 9;
+    const int chunk16 = chunk32 * 2 + (g >> 1);
+    const float* src = w + (size_t)row * Kp + (size_t)(chunk16 * 9 + tap) * 16 + (g & 1) * 8;
+    bf16x8 p1, p2, p3;
+    split3(*(const f32x4*)src, *(const f32x4*)(src + 4), p1, p2, p3);
+    const int j = rl >> 4, l = (rl & 15) + 16 * g;
+    unsigned char* dst = out + ((size_t)tile * nsteps + s) * BN * 192 + (size_t)j * 3 * 1024 + (size_t)l * 16;
+    *(bf16x8*)(dst) = p1; *(bf16x8*)(dst + 1024) = p2; *(bf16x8*)(dst + 2048) = p3;
+  }
+}
+
+template <int TH, int BN, int WAVES_M, int WAVES_N>
+int launch(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int HR = (TH + 2) * 34, NPIX = (HR + 15) / 16 * 16;
+  a.tiles_x = (a.GW + 31) / 32;
+  a.tiles_y = (a.GH + TH - 1) / TH;
+  static const int swz = [] { const char* e = getenv("SSG_XCD_SWIZZLE"); return e ? atoi(e) : 1; }();
+  a.xcd_swizzle = swz;
+  a.ntiles_n = a.Cout / BN;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
+  constexpr int lds_bytes = 3 * 4 * NPIX * 16 + 3 * BN * 192;
+  static_assert(lds_bytes <= 160 * 1024 && (NW == 8 || lds_bytes <= 80 * 1024), "LDS budget");
+  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (attr != hipSuccess) { ssg_set_error("conv halo k32: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
+  hipLaunchKernelGGL((conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N>), grid, dim3(NW * 64), lds_bytes, st, a);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}
+
+}  // namespace
+
+// Split-pack format code of the k32 kernel for this launch, or 0 when it does not take it: 1128 = 8 x 32-pixel tiles x 128
+// channels (512 threads, one workgroup per CU), 1064 = 4 x 32 x 64 (256 threads, two per CU).  Needs whole 32-channel chunks on
+// both inputs, whole column tiles, 16-byte-aligned rows everywhere, and -- a tile per CU being a lot of work -- a grid that
+// fills the chip evenly.  SSG_K32=0 switches the family off (A/B), SSG_K32=2 forces it where the shape is legal.
+static int g_k32_mode = -1;                               // -1: not read yet; SSG_K32 or ssg_conv_set_k32_mode
+extern "C" int ssg_conv_set_k32_mode(int mode) {          // 0 = off, 1 = where the grid fills the chip (default), 2 = wherever legal (tests)
+  const int old = g_k32_mode;
+  g_k32_mode = mode;
+  return old;
+}
+
+int ssg_conv_halo_k32_fmt(const ConvArgs& a) {
+  if (g_k32_mode < 0) { const char* e = getenv("SSG_K32"); g_k32_mode = e ? atoi(e) : 1; }
+  const int on = g_k32_mode;
+  if (!on || !ssg_conv_halo_ok(a) || a.parity) return 0;
+  if ((a.C1 & 31) || (a.C2 & 31) || a.GW < 17) return 0;
+  if ((a.ldo & 3) || ((uintptr_t)a.out & 15) || (a.res && ((a.ldr & 3) || ((uintptr_t)a.res & 15))) || (a.bias && ((uintptr_t)a.bias & 15))) return 0;
+  const unsigned long long bytes = (unsigned long long)a.N * a.H * a.W * (unsigned long long)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4ull;
+  if (bytes > 0xfffffff0ull) return 0;                  // 32-bit byte offsets of the buffer descriptors
+  if (a.Cout % 128 == 0) {
+    const long long wgs = (long long)a.N * ((a.GH + 7) / 8) * ((a.GW + 31) / 32) * (a.Cout / 128);
+    const long long waves = (wgs + 255) / 256;
+    if (on == 2 || wgs >= 2048 || (wgs >= 256 && wgs * 10 >= waves * 256 * 8)) return 1128;   // >= 80 % of the last wave of tiles filled
+  }
+  if (a.Cout % 64 == 0) {
+    const long long wgs = (long long)a.N * ((a.GH + 3) / 4) * ((a.GW + 31) / 32) * (a.Cout / 64);
+    if (on == 2 || wgs >= 1536) return 1064;
+  }
+  return 0;
+}
+
+void ssg_conv_halo_k32_tile(int fmt, int* th, int* tw) { *tw = 32; *th = fmt == 1128 ? 8 : 4; }
+
+int ssg_conv_igemm_halo_k32_launch(const ConvArgs& a, int fmt, hipStream_t st) {
+  if (fmt == 1128) return launch<8, 128, 4, 2>(a, st);
+  if (fmt == 1064) return launch<4, 64, 2, 2>(a, st);
+  ssg_set_error("conv halo k32: unknown format %d", fmt);
+  return SSG_EINVAL;
+}
+
+int ssg_pack_split_k32_launch(const float* w_packed, int R, int Kp, int BN, void* out, hipStream_t st) {
+  const long long total = (long long)(R / BN) * BN * (Kp >> 5) * 4;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pack_split_k32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w_packed, R, Kp, BN, (unsigned char*)out);
+  SSG_LAUNCH_CHECK();
+  return SSG_OK;
+}

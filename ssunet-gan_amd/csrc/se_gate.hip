@@ -212,6 +212,7 @@ extern "C" int ssg_se_gate_fwd_f32(const float* sq, int ldq, int N, int C, const
                                    int S, float* h_pre, float* gate, int ldg, float* tmp, void* stream) {
   SSG_REQUIRE(sq && w1 && w2 && h_pre && gate && tmp, SSG_EINVAL, "se_gate: null pointer");
   SSG_REQUIRE(se_shape_ok(N, C, S) && ldq >= C && ldg >= C, SSG_EINVAL, "se_gate: N=%d C=%d S=%d outside the kernel's range (N <= 16, S <= 256, N*S <= 2048)", N, C, S);
+  SSG_REQUIRE((S & 3) != 0 || ssg_aligned16(w2), SSG_EALIGN, "se_gate: w2 rows are read 16 B at a time when S %% 4 == 0: w2 must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int nck = (C + SE_CK - 1) / SE_CK;
   hipLaunchKernelGGL(se_hidden_part_kernel, dim3((unsigned)((N * S + 255) / 256), (unsigned)nck), dim3(256), 0, st, sq, ldq, N, C, w1, S, tmp);
@@ -226,6 +227,7 @@ extern "C" int ssg_se_gate_bwd_f32(const float* dgate, int ldd, const float* gat
                                    float* tmp, void* stream) {
   SSG_REQUIRE(dgate && gate && h_pre && sq && w1 && w2 && dsq && dw1 && dw2 && tmp, SSG_EINVAL, "se_gate_bwd: null pointer");
   SSG_REQUIRE(se_shape_ok(N, C, S) && ldd >= C && ldg >= C && ldq >= C && lds_ >= C, SSG_EINVAL, "se_gate_bwd: N=%d C=%d S=%d outside the kernel's range", N, C, S);
+  SSG_REQUIRE((S & 3) != 0 || (ssg_aligned16(w2) && ssg_aligned16(dw2)), SSG_EALIGN, "se_gate_bwd: w2 / dw2 rows are accessed 16 B at a time when S %% 4 == 0: both must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int nck = (C + SE_CK - 1) / SE_CK;
   float* part = tmp;                                     // [nck][N][S]

@@ -318,6 +318,8 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
         label = _CONV_LABELS.get(call('ssg_conv2d_kernel_id', C.byref(d)), '?') + ('+splitk' if ws is not None else '')
         if parity_merge:
             label = 'conv_igemm_halo_x3_kernel<128,64,4,1,true>'
+        elif split is not None and bn >= 1000:
+            label = 'conv_halo_k32_kernel<8,128>' if bn == 1128 else 'conv_halo_k32_kernel<4,64>'
         elif split is not None:
             if 'halo' in label:
                 label = label.replace('conv_igemm_halo_kernel', 'conv_igemm_halo_x3_kernel').replace('<256,64>', '<128,64>')
@@ -414,7 +416,11 @@ def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None, wscale
             taps = [(ky, kx, (py + pt - ky) // s, (px + pl - kx) // s) for ky in range(kh) for kx in range(kw)
                     if (py + pt - ky) % s == 0 and (px + pl - kx) % s == 0]
             classes.append((py, px, taps))
-    if PARITY_MERGE and s == 2 and kh == 3 and kw == 3 and (pt, pl) == (1, 1) and MFMA_SPLIT:
+    # eligibility of the merged launch is decided BEFORE its 9-tap pack is built: the library declines dy narrower
+    # than 17 pixels, channel counts that are not whole 64-column tiles and tensors beyond 32-bit byte offsets
+    # (ssg_conv_halo_x3_parity_ok); with spectral norm a declined pack would be an uncached launch + allocation per backward
+    if (PARITY_MERGE and s == 2 and kh == 3 and kw == 3 and (pt, pl) == (1, 1) and MFMA_SPLIT and ow >= 17
+            and (c_hi - c_lo) % 64 == 0 and dy.numel() * 4 <= 0xfffffff0 and _os.environ.get('SSG_X3_PARITY', '1') != '0'):
         # the four classes read the same 2x2 neighbourhood of dy: one launch, nine tap steps, four accumulator sets
         # (conv_igemm_halo_x3_kernel<..., PARITY>); falls through to the per-class launches where the library declines
         merged = [t for _, _, taps in classes for t in taps]

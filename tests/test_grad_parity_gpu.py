@@ -223,59 +223,58 @@ def test_step_gradients_vs_fp64_on_the_same_activation_pattern(pkg, dev):
         assert not bad, 'G-step gradient digests vs golden (no pattern difference in this run): %s' % bad[:5]
 
 
-def test_config1_logits_on_the_same_activation_pattern(pkg, dev):
-    """VERDICT r2 item 6: BASELINE config 1 (4 x 3 x 256 x 256) with the tool above instead of the quantile bounds of
-    test_step_gpu.py.  The fp32 oracle follows the HIP forward's activation pattern (22 BasicBlock ReLUs, 11 SPADE ReLUs, 5 pool
-    argmax planes) and records what IT computes at every decision.  Then
+def _same_pattern_forward(pkg, dev, n, hw, gold_name, ds):
+    """The fp32 oracle follows the HIP forward's activation pattern (22 BasicBlock ReLUs, 11 SPADE ReLUs, 5 pool argmax planes)
+    and hands over what IT computes at every decision (streamed: nothing but counters is retained).  Then
       (1) every HIP decision that differs from the oracle's own choice AT THAT POINT -- upstream decisions being identical -- is a
           near-tie of the oracle's value (a flip upstream legitimately moves everything downstream, which is why the raw
-          pattern comparison of the 64^2 test cannot be used at this size);
+          pattern comparison of the 64^2 test cannot be used at these sizes);
       (2) the oracle's logits on the HIP pattern equal the HIP logits to max-abs 2e-4: every logit that deviates from the
           reference by more does so through a near-tie, not through arithmetic;
       (3) the number of flips per decision point stays inside the oracle's own near-tie census there."""
     from oracle import seg_gan_cpu as O
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
-    inp, _ = O.synthetic_batch(4, 256, 256)
+    inp, _ = O.synthetic_batch(n, hw, hw)
     torch.manual_seed(41)
     G = pkg.models_seg_gan.Generator(dict(arch='UNet_R_SS_v2', num_classes=3, input_channels=3, deep_supervision=False)).to(dev).train()
-    with torch.no_grad(), _Capture(pkg) as cap:
-        hip_logits = G(inp.to(dev)).cpu()
+    pkg.ops.PROFILE = []
+    try:
+        with torch.no_grad(), _Capture(pkg) as cap:
+            hip_logits = G(inp.to(dev)).cpu()
+        labels = set(rec[0] for rec in pkg.ops.PROFILE)
+    finally:
+        pkg.ops.PROFILE = None
     hip_items = cap.items
+    del G
+    torch.cuda.empty_cache()
 
     Gc, _, _, _ = O.make_models()
     Gc.train()
     with torch.no_grad():
         ref_logits = Gc(inp)
-    gold = np.load(os.path.join(GOLDEN, 'step_n4_256.npz'))
-    assert np.abs(ref_logits.numpy()[:, :, ::8, ::8] - gold['s0_logits_ds']).max() < 1e-5, 'oracle forward is not the reference\'s'
+    del Gc
+    gold = np.load(os.path.join(GOLDEN, gold_name))
+    assert np.abs(ref_logits.numpy()[:, :, ::ds, ::ds] - gold['s0_logits_ds']).max() < 1e-5, 'oracle forward is not the reference\'s'
     e_ref = (hip_logits - ref_logits).abs()
     print('HIP vs reference logits: median %.2e, max %.2e, > 1e-2: %d of %d' % (e_ref.median().item(), e_ref.max().item(), int((e_ref > 1e-2).sum()), e_ref.numel()))
+    del ref_logits
 
-    Gi, _, _, _ = O.make_models()
-    Gi.train()
-    pat = O.ActivationPattern('impose', [t.clone() for t in hip_items], keep=True)
-    O.PATTERN = pat
-    try:
-        with torch.no_grad():
-            imposed = Gi(inp)
-    finally:
-        O.PATTERN = None
-    assert len(pat.seen) == len(hip_items)
-    n_dec = n_flip = 0
+    tally = dict(n_dec=0, n_flip=0)
     census = []
-    for k, (x, h) in enumerate(zip(pat.seen, hip_items)):
+
+    def check(k, x, h):
         if h.dtype == torch.bool:
             diff = (x > 0) != h
-            n_dec += x.numel()
+            tally['n_dec'] += x.numel()
             if diff.any():
                 worst = x[diff].abs().max().item()
                 assert worst < ACT_NEAR_TIE, 'item %d: activation mask differs at |pre-activation| = %.3e (not a near-tie)' % (k, worst)
-                n_flip += int(diff.sum()); census.append((k, 'act', int(diff.sum()), int((x.abs() < ACT_NEAR_TIE).sum()), worst))
+                tally['n_flip'] += int(diff.sum()); census.append((k, 'act', int(diff.sum()), int((x.abs() < ACT_NEAR_TIE).sum()), worst))
         else:
-            n, c, hh, ww = x.shape
-            xs = x.unfold(2, 2, 2).unfold(3, 2, 2).reshape(n, c, hh // 2, ww // 2, 4)
+            nn_, c, hh, ww = x.shape
+            xs = x.unfold(2, 2, 2).unfold(3, 2, 2).reshape(nn_, c, hh // 2, ww // 2, 4)
             diff = xs.argmax(-1) != h
-            n_dec += h.numel()
+            tally['n_dec'] += h.numel()
             if diff.any():
                 top2 = xs.topk(2, dim=-1).values
                 gaps = top2[..., 0] - top2[..., 1]
@@ -283,12 +282,40 @@ def test_config1_logits_on_the_same_activation_pattern(pkg, dev):
                 chosen = xs.gather(-1, h.unsqueeze(-1)).squeeze(-1)
                 short = (top2[..., 0] - chosen)[diff].max().item()
                 assert short < POOL_NEAR_TIE, 'item %d: pool argmax differs, %.3e below the maximum (not a near-tie)' % (k, short)
-                n_flip += int(diff.sum()); census.append((k, 'pool', int(diff.sum()), int((gaps < POOL_NEAR_TIE).sum()), short))
-    print('config 1: %d decisions of %d differ from the oracle\'s own choice on the same upstream pattern; per item (item, kind, flips, '
-          'near-ties there, worst margin): %s' % (n_flip, n_dec, census))
+                tally['n_flip'] += int(diff.sum()); census.append((k, 'pool', int(diff.sum()), int((gaps < POOL_NEAR_TIE).sum()), short))
+
+    Gi, _, _, _ = O.make_models()
+    Gi.train()
+    pat = O.ActivationPattern('impose', hip_items, keep=check)
+    O.PATTERN = pat
+    try:
+        with torch.no_grad():
+            imposed = Gi(inp)
+    finally:
+        O.PATTERN = None
+    assert len(pat.seen) == len(hip_items)
+    n_dec, n_flip = tally['n_dec'], tally['n_flip']
+    print('%d x %d^2: %d decisions of %d differ from the oracle\'s own choice on the same upstream pattern; per item (item, kind, flips, '
+          'near-ties there, worst margin): %s' % (n, hw, n_flip, n_dec, census))
     for _, _, flips, near, _ in census:
         assert flips <= near
     assert n_flip < 1e-4 * n_dec
     e = (hip_logits - imposed).abs()
     print('HIP vs fp32 oracle on the HIP pattern: median %.2e, max %.2e' % (e.median().item(), e.max().item()))
     assert e.max().item() <= 2e-4, 'arithmetic difference on the same piece: max %.3e' % e.max().item()
+    return labels
+
+
+def test_config1_logits_on_the_same_activation_pattern(pkg, dev):
+    """VERDICT r2 item 6: BASELINE config 1 (4 x 3 x 256 x 256) with the tool above instead of the quantile bounds of
+    test_step_gpu.py."""
+    _same_pattern_forward(pkg, dev, 4, 256, 'step_n4_256.npz', 8)
+
+
+def test_config2_logits_on_the_same_activation_pattern_bench_size(pkg, dev):
+    """the same comparison at the BENCH size, 16 x 3 x 512 x 512 (BASELINE config 2), with the split-operand
+    kernels on -- the only size that reaches the >= 2^22-pixel dispatch rules, the 512^2 tiles of the 64-channel layers and the
+    1024-part reducers.  2.2e9 decisions; the oracle's values are checked as they are computed (nothing retained)."""
+    assert pkg.ops.MFMA_SPLIT, 'the bench-size comparison is of the default (split-operand) kernels'
+    labels = _same_pattern_forward(pkg, dev, 16, 512, 'step_n16_512.npz', 8)
+    assert any('x3' in l or 'x3k' in l for l in labels), 'no split-operand kernel ran: %s' % sorted(labels)

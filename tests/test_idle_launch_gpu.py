@@ -32,12 +32,12 @@ def _same(results, what):
 
 @pytest.mark.parametrize('split', [True, False], ids=['split', 'fp32mfma'])
 @pytest.mark.parametrize('c1,c2,co,hw,stride', [(128, 0, 128, 128, 1), (64, 128, 128, 128, 1), (128, 0, 128, 128, 2), (64, 0, 64, 256, 1)])
-def test_conv_fwd_dgrad_wgrad_after_idle(c1, c2, co, hw, stride, split):
+def test_conv_fwd_dgrad_wgrad_after_idle(c1, c2, co, hw, stride, split, monkeypatch):
     import ssunet_gan_amd as S
     from ssunet_gan_amd import ops
     if split and stride != 1:
         pytest.skip('stride 2 has no split-operand kernel')
-    saved, ops.MFMA_SPLIT = ops.MFMA_SPLIT, split
+    monkeypatch.setattr(ops, 'MFMA_SPLIT', split)      # restored on every exit path
     from ssunet_gan_amd._lib import ACT_NONE
     dev = torch.device('cuda')
     torch.manual_seed(3)
@@ -57,7 +57,6 @@ def test_conv_fwd_dgrad_wgrad_after_idle(c1, c2, co, hw, stride, split):
         _idle()
         dws.append(ops._conv_wgrad_impl(x1, x2, dy, tuple(w.shape), stride, 1))
     torch.cuda.synchronize()
-    ops.MFMA_SPLIT = saved
     _same(outs, 'conv forward'); _same(dxs, 'input gradient'); _same(dws, 'weight gradient')
     ref = F.conv2d(xc[:2], w.cpu(), None, stride, 1)
     err = (outs[0][:2].cpu() - ref).abs().max().item()

@@ -110,14 +110,14 @@ def _split_label(name):
 
 @pytest.mark.parametrize('split', [True, False], ids=['split', 'fp32mfma'])
 @pytest.mark.parametrize('case', KERNEL_CASES)
-def test_conv2d_specialised_kernels(pkg, dev, case, split):
+def test_conv2d_specialised_kernels(pkg, dev, case, split, monkeypatch):
     n, cin, cout, h, w, k, p, expect = case
     if split:
         if not any(_split_label(e) != e for e in expect):
             pytest.skip('no split-operand kernel on this case')
         # the split conv kernels take whole 64 / 128-column tiles (other Cout stay on the fp32 MFMA); the weight gradient always splits
         expect = tuple(_split_label(e) if (cout % 64 == 0 or e.startswith('wgrad')) else e for e in expect)
-    pkg.ops.MFMA_SPLIT, saved_split = split, pkg.ops.MFMA_SPLIT
+    monkeypatch.setattr(pkg.ops, 'MFMA_SPLIT', split)      # restored on every exit path
     g = torch.Generator().manual_seed(1234 + cin + cout)
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
@@ -140,7 +140,6 @@ def test_conv2d_specialised_kernels(pkg, dev, case, split):
         labels = [rec[0] for rec in pkg.ops.PROFILE]
     finally:
         pkg.ops.PROFILE = None
-        pkg.ops.MFMA_SPLIT = saved_split
     for name in expect:
         assert name in labels, '%s did not run (ran: %s)' % (name, labels)
     _close(yd, yr, 1e-5, 2e-6 * math.sqrt(cin * k * k), 'fwd')
