@@ -41,6 +41,13 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6      # dense bf16: 1024 SIMDs x 1024 FLOP/clk x 2
 SPLIT_TERMS = 6                     # bf16 MFMAs a split-operand kernel executes per algorithmic fp32 MFMA step (conv_igemm_halo_x3.hip)
 
 
+def is_split_kernel(label):
+    """Kernels that multiply fp32 operands as three bf16 terms on the bf16 matrix pipe: the 16-channel-chunk x3 family
+    (v_mfma_f32_32x32x16_bf16) and the round-4 k32 family (conv_igemm_halo_k32.hip / conv_wgrad_k32.hip, v_mfma_f32_16x16x32_bf16)."""
+    return '_x3_' in label or 'k32' in label
+
+
+
 def _norm_symbol(name):
     """'void (anonymous namespace)::conv_igemm_halo_kernel<128, 128, 2, 2>(ConvArgs)' -> 'conv_igemm_halo_kernel<128,128,2,2>'."""
     name = name.split('::')[-1].split('(')[0]
@@ -123,9 +130,13 @@ def measured_ceilings(S, dev):
     data = torch.randn(4096 * 8, device=dev).to(torch.bfloat16)
     ms = timeit(lambda: call('ssg_tool_mfma_peak_bf16_data', ptr(scratch), 768, 100 * it, ptr(data), stream_ptr()), 2)
     mfma16r = 768 * 4 * 100 * it * 16 * 32768 / ms / 1e9
-    a = torch.empty(1 << 27, device=dev); b = torch.empty(1 << 27, device=dev)
+    ms = timeit(lambda: call('ssg_tool_mfma_peak_bf16_data16', ptr(scratch), 768, 100 * it, ptr(data), stream_ptr()), 2)
+    mfma16r16 = 768 * 4 * 100 * it * 16 * 32768 / ms / 1e9
+    a = torch.empty(1 << 28, device=dev); b = torch.empty(1 << 28, device=dev)      # 1 GiB each: far beyond the 256-MB Infinity Cache
     ms = timeit(lambda: call('ssg_tool_copy_f32', ptr(a), ptr(b), a.numel(), stream_ptr()), 3)
-    return {'mfma_f32_tflops': round(mfma, 1), 'mfma_bf16_tflops': round(mfma16, 1), 'mfma_bf16_random_operand_tflops': round(mfma16r, 1), 'hbm_copy_tbps': round(2 * a.numel() * 4 / ms / 1e9, 2)}
+    return {'mfma_f32_tflops': round(mfma, 1), 'mfma_bf16_tflops': round(mfma16, 1), 'mfma_bf16_random_operand_tflops': round(mfma16r, 1),
+            'mfma_bf16_16x16x32_random_operand_tflops': round(mfma16r16, 1), 'hbm_copy_tbps': round(2 * a.numel() * 4 / ms / 1e9, 2),
+            'hbm_copy_form': 'one float4 per thread, non-temporal, 1 GiB -> 1 GiB (the grid-stride probe of rounds 1-3 read 4.6-4.8)'}
 
 
 def host_cores():
@@ -394,7 +405,7 @@ def main():
             now = csrc_sha1()
             def kernel_entry(k, v):
                 e = {'tflops': round(v[0] / v[1] / 1e12, 2), 'time_frac_of_step': round(v[1] / dt, 4), 'launches': v[2]}
-                if '_x3_' in k:         # fp32 operands split into three bf16 terms: 6 bf16 MFMAs per algorithmic fp32 MFMA step
+                if is_split_kernel(k):         # fp32 operands split into three bf16 terms: 6 bf16 MFMAs per algorithmic fp32 MFMA step
                     e['pipe'] = 'bf16 (3-term split, fp32 accumulate)'
                     e['executed_mfma_tflops'] = round(SPLIT_TERMS * v[0] / v[1] / 1e12, 1)
                     e['executed_frac_of_bf16_peak'] = round(SPLIT_TERMS * v[0] / v[1] / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
@@ -403,7 +414,7 @@ def main():
             # kernel multiplies on, in the same algorithmic unit: the fp32 MFMA peak for a v_mfma_f32_32x32x2_f32 kernel; for a
             # split-operand kernel the dense bf16 MFMA peak / 6 (six bf16 MFMAs of the same shape stand for one fp32 product:
             # DESIGN.md 3.9) -- `executed` restates that in executed bf16 FLOP/s, `frac_of_fp32_mfma_peak` against the fp32 pipe.
-            split_dom = '_x3_' in label
+            split_dom = is_split_kernel(label)
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS if split_dom else PEAK_FP32_MFMA_TFLOPS
             roof = {'bound': 'mfma', 'kernel': label, 'achieved': round(ach, 2), 'peak': round(peak, 1),
                     'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
@@ -419,7 +430,7 @@ def main():
                     'step_frac_of_fp32_mfma_roofline': round(value * FLOP_PER_IMG_512 * (args.size / 512.0) ** 2 / 1e12 / PEAK_FP32_MFMA_TFLOPS / world, 4)}
             roof['step_frac_of_conv_roofline'] = roof['step_frac_of_fp32_mfma_roofline']       # the name rounds 1-2 reported
             if split_dom:
-                roof['executed'] = {'pipe': 'bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 operands split into 3 bf16 terms, 6 of the 9 products, fp32 accumulate',
+                roof['executed'] = {'pipe': 'bf16 MFMA (%s), fp32 operands split into 3 bf16 terms, 6 of the 9 products, fp32 accumulate' % ('v_mfma_f32_16x16x32_bf16' if 'k32' in label else 'v_mfma_f32_32x32x16_bf16'),
                                     'achieved': round(SPLIT_TERMS * ach, 1), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': round(SPLIT_TERMS * ach / PEAK_BF16_MFMA_TFLOPS, 4)}
         line = {
@@ -468,8 +479,8 @@ def main():
             line['measured_ceilings'] = measured_ceilings(S, dev)
             # the split kernels against what the bf16 pipe of THIS device sustains on random operands (power-limited: DESIGN.md 3.9)
             if roof and roof.get('executed') and line['measured_ceilings'].get('mfma_bf16_random_operand_tflops'):
-                roof['executed']['frac_of_measured_random_operand_rate'] = round(
-                    roof['executed']['achieved'] / line['measured_ceilings']['mfma_bf16_random_operand_tflops'], 4)
+                key = 'mfma_bf16_16x16x32_random_operand_tflops' if 'k32' in roof['kernel'] else 'mfma_bf16_random_operand_tflops'
+                roof['executed']['frac_of_measured_random_operand_rate'] = round(roof['executed']['achieved'] / line['measured_ceilings'][key], 4)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -97,8 +97,9 @@ typedef struct {
  * ABI 7 (round 4): ssg_conv2d_split_bn may also return 1128 or 1064 -- the launch goes to the 32-channel-chunk kernel on
  * v_mfma_f32_16x16x32_bf16 (conv_igemm_halo_k32.hip: 8 x 32-pixel x 128-channel tiles of 512 threads, or 4 x 32 x 64 of 256), whose
  * weights are packed by the same two functions with BN = that code: layout [R/bn][Kp/32 steps = chunk32 * 9 + tap][bn/16
- * fragments][3 planes][64 lanes][16 B] (bn = code - 1000; R % bn == 0, Kp % 288 == 0).  ssg_conv_set_k32_mode(0 / 1 / 2): never /
- * where the grid fills the chip (default, SSG_K32) / wherever the shape is legal (tests); returns the previous mode. */
+ * fragments][3 planes][64 lanes][16 B] (bn = code - 1000; R % bn == 0, Kp % 288 == 0).  A third code, 2064 (16 x 32-pixel x 64-channel
+ * tiles of 512 threads), reads the pack of 1064: pack with BN = 1064.  ssg_conv_set_k32_mode(0 / 1 / 2): never /
+ * where the grid fills the chip (default, SSG_K32) / wherever the shape is legal (tests). */
 int ssg_conv2d_split_bn(const ssg_conv_desc* d);
 int ssg_conv_set_k32_mode(int mode);
 int64_t ssg_pack_weights_split_bytes(int R, int Kp, int BN);
@@ -168,6 +169,10 @@ int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream);
  * 15/16 = wgrad4_kernel (4x4x1 MFMA: dout <= 4 channels / in = 4 channels, the default for
  * those shapes), 13/14 = the opt-in VALU variants */
 int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d);
+/* 60 = wgrad_k32_kernel (conv_wgrad_k32.hip, round 4): the split-operand weight gradient of 3x3 stride-1 convs on
+ * v_mfma_f32_16x16x32_bf16 (64-channel multiples on every side; flags bit 0).  ssg_wgrad_set_k32_mode(0 / 1) switches it off / on
+ * at run time (default on, SSG_WGRAD_K32). */
+int ssg_wgrad_set_k32_mode(int mode);
 
 /* Attention gate of AttUNet (archs.py:115-144, `x * psi`): y[p][c] = x[p][c] * sigmoid(g[p]) with one gate
  * logit per pixel (g is the 1-channel BatchNorm output, pixel stride ldg); the sigmoid is folded in.
@@ -456,7 +461,8 @@ int ssg_tool_mfma_peak_f32(float* scratch, int blocks, int iters, void* stream);
 int ssg_tool_mfma_peak_bf16(float* scratch, int blocks, int iters, void* stream);
 /* ... on caller operands (`data`: 64 KiB of bf16 values), which toggle the multiplier inputs: the power-limited rate */
 int ssg_tool_mfma_peak_bf16_data(float* scratch, int blocks, int iters, const void* data, void* stream);
-int ssg_tool_copy_f32(const float* src, float* dst, int64_t n, void* stream);
+int ssg_tool_mfma_peak_bf16_data16(float* scratch, int blocks, int iters, const void* data, void* stream);   /* the same on v_mfma_f32_16x16x32_bf16 */
+int ssg_tool_copy_f32(const float* src, float* dst, int64_t n, void* stream);   /* one float4 per thread, non-temporal */
 
 #ifdef __cplusplus
 }

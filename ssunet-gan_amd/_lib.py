@@ -77,6 +77,7 @@ SIGNATURES = {
     'ssg_conv2d_split_bn': [C.POINTER(ConvDesc)],
     'ssg_pack_weights_split_bytes': [_I, _I, _I],
     'ssg_conv_set_k32_mode': [_I],
+    'ssg_wgrad_set_k32_mode': [_I],
     'ssg_pack_weights_split_bf16x3': [_P, _I, _I, _I, _P, _P],
     'ssg_bn_stats_from_partials_workspace_bytes': [_I, _I],
     'ssg_bn_stats_from_partials_f32': [_P, _I, _I, _P, _D, _P, _P],
@@ -157,6 +158,7 @@ SIGNATURES = {
     'ssg_tool_mfma_peak_f32': [_P, _I, _I, _P],
     'ssg_tool_mfma_peak_bf16': [_P, _I, _I, _P],
     'ssg_tool_mfma_peak_bf16_data': [_P, _I, _I, _P, _P],
+    'ssg_tool_mfma_peak_bf16_data16': [_P, _I, _I, _P, _P],
     'ssg_tool_copy_f32': [_P, _P, _L, _P],
 }
 

@@ -19,6 +19,7 @@ struct ConvArgs {
   int ntiles_n, xcd_swizzle;     // conv_igemm_dma.hip: Cout tiles (fastest workgroup index), XCD-contiguous tile map
   float* ws; int ksplit;         // conv_igemm_halo.hip: split-K slabs [ksplit][N*GH*GW][pad4(Cout)] (ksplit <= 1: off)
   int parity;                    // ssg_conv_desc.parity_merge
+  const float* w32;              // split-operand launches: the fp32 packed weights (ssg_conv_desc.w) beside the split pack in `w` (conv_slow.h)
 };
 
 

@@ -292,6 +292,7 @@ ConvArgs to_args(const ssg_conv_desc* d) {
   a.tiles_x = a.tiles_y = 0;
   a.ws = nullptr; a.ksplit = 1;
   a.parity = d->parity_merge;
+  a.w32 = d->w;
   return a;
 }
 
@@ -302,9 +303,9 @@ int split_bn(const ssg_conv_desc* d) {
   if (d->parity_merge) return ssg_conv_halo_x3_parity_ok(a) ? 64 : 0;
   if (!uses_halo(a)) return ssg_conv_dma_x3_bn(a);            // 1x1, stride 2, parity-class launches: the LDS-DMA pipeline
   if (!ssg_conv_halo_x3_ok(a, pick_variant(d))) return 0;
-  if (d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) && ssg_conv_halo_ksplit(a, pick_variant(d)) > 1) return 0;   // small grids keep split-K
-  const int k32 = ssg_conv_halo_k32_fmt(a);                     // 1128 / 1064: the 32-channel-chunk kernel and its pack format
+  const int k32 = ssg_conv_halo_k32_fmt(a);                     // 1128 / 1064: the 32-channel-chunk kernel and its pack format (grids that fill the chip, or forced)
   if (k32) return k32;
+  if (d->ldo % 4 == 0 && !((uintptr_t)d->out & 15) && ssg_conv_halo_ksplit(a, pick_variant(d)) > 1) return 0;   // small grids keep split-K
   return ssg_conv_halo_x3_bn(a, pick_variant(d));
 }
 

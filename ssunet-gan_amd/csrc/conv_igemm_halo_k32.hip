@@ -24,11 +24,20 @@
 #include "lds_dma.h"
 #include "conv_args.h"
 #include "mfma_split.h"
+#include "conv_slow.h"
 #include <stdlib.h>
 
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef SSG_K32_PROBE
+// diagnostic build only (tools/k32_probe.py): per workgroup s_memtime at kernel start / loop start / loop end / kernel end
+__device__ unsigned long long* ssg_probe_buf_k32 = nullptr;
+#define SSG_STAMP(i) do { if (ssg_probe_buf_k32 && tid == 0) ssg_probe_buf_k32[4 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SSG_STAMP(i) do { } while (0)
+#endif
 
 template <int TH, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 1 : 2) void conv_halo_k32_kernel(const ConvArgs a) {
@@ -40,18 +49,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   constexpr int IMG = 3 * PLANE;
   constexpr int BSTG = BN * 192;                         // bytes of one weight stage (one tap x 32 channels x 3 planes)
   constexpr int BPIECES = BSTG / 1024;
-  constexpr int B_PC = BPIECES / NW;
+  constexpr int B_PC = (BPIECES + NW - 1) / NW;          // per wave and step; piece indices >= BPIECES are dummies (<16, 64>: 12 pieces, 8 waves)
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / 16, NI = WTN / 16;
   constexpr int NBLK = (HR + 63) / 64, ITEMS = NBLK * 4, IPW = ITEMS / NW, NLD = 2 * IPW;
   constexpr int LD_T = 4;                                // tap step at which the next chunk's pixel loads are issued
-  static_assert(BPIECES % NW == 0 && ITEMS % NW == 0, "uniform DMA pieces / load items per wave");
+  static_assert(ITEMS % NW == 0, "uniform load items per wave");
   static_assert(IMG % 1024 == 0, "the ring behind the image stays 1-KiB aligned");
   static_assert(WTM == 64, "a wave owns two 32-pixel tile rows");
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   unsigned char* const img = lds;
   unsigned char* const ring = lds + IMG;
+  unsigned char* const ldsDummy = ring + 3 * BSTG;       // 1 KiB: target of the dummy pieces
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,7 +148,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
     for (int j = 0; j < B_PC; ++j) {
       const int g = wave + NW * j;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (ssg_lds_void*)(st + g * 1024), 16, (unsigned)lane * 16u, so + g * 1024, 0, 0);
+      if (BPIECES % NW == 0 || g < BPIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (ssg_lds_void*)(st + g * 1024), 16, (unsigned)lane * 16u, so + g * 1024, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (ssg_lds_void*)ldsDummy, 16, OOB, 0, 0, 0);      // every lane out of range: keeps vmcnt uniform
     }
   };
 
@@ -157,12 +168,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   const int wfrag = wn * NI * 3 * 1024 + lane * 16;      // this lane's 16 bytes of fragment (wn * NI + j), plane q: + (j * 3 + q) * 1024
 
   // ---- prologue: pixels of chunk 0 (loads first: they are the oldest vmcnt entries), two weight steps in flight
+  SSG_STAMP(0);
   load_px(0);
   issue_b(0);
   issue_b(1);
   wait_vmcnt<2 * B_PC>();
   convert_px();
   write_px();
+  SSG_STAMP(1);
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
 #pragma unroll
@@ -204,11 +217,45 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       SSG_K32_TERM(1, 0) SSG_K32_TERM(0, 1)
       SSG_K32_TERM(0, 0)
 #undef SSG_K32_TERM
-      if (t == 8) convert_px();                          // the loads of LD_T landed before tap 7's barrier; VALU work beside the MFMAs
+      if (t == 8) {                                      // the loads of LD_T landed before tap 7's barrier
+        __builtin_amdgcn_sched_barrier(0);               // after the last MFMA is issued: the fragments are dead, no extra register pressure
+        convert_px();
+      }
     }
   }
   wait_vmcnt<0>();
   wait_lds_reads();
+  SSG_STAMP(2);
+
+  // ---- non-finite operands (conv_slow.h): a workgroup that holds a non-finite accumulator recomputes its tile with fp32 FMAs
+  {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad |= ssg_nonfinite(acc[i][j][r]);
+    if (__syncthreads_or(bad)) {                         // also: every wave has left the main loop, LDS is scratch
+      float* scr = (float*)lds + tid;                    // value e of this thread at scr[e * threads]
+      // the argument block is re-read from the kernarg segment HERE (opaque pointer): kept live in SGPRs across the main loop for
+      // this cold path, its fields spilled 6 registers of the hot loop
+      const ConvArgs* ap = (const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ap));
+      const ConvArgs& as = *ap;
+      for (int e = 0; e < MI * NI * 4; ++e) {
+        const int i = e / (NI * 4), j = (e >> 2) % NI, r = e & 3;
+        const int p = wm * WTM + i * 16 + l15;
+        scr[e * (NW * 64)] = ssg_conv_slow_value(as, n, ty * TH + (p >> 5), tx * TW + (p & 31), n0 + wn * WTN + j * 16 + kg * 4 + r, 0, 9);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = scr[((i * NI + j) * 4 + r) * (NW * 64)];
+    }
+  }
 
   // ---- epilogue.  acc[i][j][r]: pixel p = wm*64 + i*16 + l15, output channel n0 + wn*WTN + j*16 + kg*4 + r.
   const bool want_bn = a.bnpart != nullptr;
@@ -282,6 +329,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       dst[n0 + tid] = t1; dst[a.Cout + n0 + tid] = t2;
     }
   }
+#ifdef SSG_K32_PROBE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the output stores have left
+  SSG_STAMP(3);
+#endif
 }
 
 // fp32 packed [R][Kp] (kmode 0 with 9 taps: k = (chunk16 * 9 + tap) * 16 + c) -> [R / BN][chunk32 * 9 + tap][BN / 16 fragments][3 planes][64 lanes][16 B]:
@@ -317,7 +368,7 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   a.xcd_swizzle = swz;
   a.ntiles_n = a.Cout / BN;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
-  constexpr int lds_bytes = 3 * 4 * NPIX * 16 + 3 * BN * 192;
+  constexpr int lds_bytes = 3 * 4 * NPIX * 16 + 3 * BN * 192 + 1024;
   static_assert(lds_bytes <= 160 * 1024 && (NW == 8 || lds_bytes <= 80 * 1024), "LDS budget");
   static const hipError_t attr = hipFuncSetAttribute((const void*)conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -329,15 +380,23 @@ int launch(const ConvArgs& a0, hipStream_t st) {
 
 }  // namespace
 
+#ifdef SSG_K32_PROBE
+extern "C" int ssg_debug_set_probe_buffer_k32(void* p) {
+  unsigned long long* v = (unsigned long long*)p;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(ssg_probe_buf_k32), &v, sizeof(v));
+}
+#endif
+
 // Split-pack format code of the k32 kernel for this launch, or 0 when it does not take it: 1128 = 8 x 32-pixel tiles x 128
-// channels (512 threads, one workgroup per CU), 1064 = 4 x 32 x 64 (256 threads, two per CU).  Needs whole 32-channel chunks on
+// channels (512 threads, one workgroup per CU), 1064 = 4 x 32 x 64 (256 threads, two per CU), 2064 = 16 x 32 x 64 (512 threads; the
+// weights are packed as for 1064).  Needs whole 32-channel chunks on
 // both inputs, whole column tiles, 16-byte-aligned rows everywhere, and -- a tile per CU being a lot of work -- a grid that
 // fills the chip evenly.  SSG_K32=0 switches the family off (A/B), SSG_K32=2 forces it where the shape is legal.
 static int g_k32_mode = -1;                               // -1: not read yet; SSG_K32 or ssg_conv_set_k32_mode
 extern "C" int ssg_conv_set_k32_mode(int mode) {          // 0 = off, 1 = where the grid fills the chip (default), 2 = wherever legal (tests)
-  const int old = g_k32_mode;
+  SSG_REQUIRE(mode >= 0 && mode <= 2, SSG_EINVAL, "k32 mode %d", mode);
   g_k32_mode = mode;
-  return old;
+  return SSG_OK;
 }
 
 int ssg_conv_halo_k32_fmt(const ConvArgs& a) {
@@ -354,17 +413,21 @@ int ssg_conv_halo_k32_fmt(const ConvArgs& a) {
     if (on == 2 || wgs >= 2048 || (wgs >= 256 && wgs * 10 >= waves * 256 * 8)) return 1128;   // >= 80 % of the last wave of tiles filled
   }
   if (a.Cout % 64 == 0) {
+    static const int t16 = [] { const char* e = getenv("SSG_K32_T16"); return e ? atoi(e) : 1; }();
+    const long long wgs16 = (long long)a.N * ((a.GH + 15) / 16) * ((a.GW + 31) / 32) * (a.Cout / 64);
+    if (t16 && a.GH >= 16 && (wgs16 >= 2048 || (on == 2 && a.GH % 16 == 0))) return 2064;   // 16 x 32-pixel x 64-channel tiles, 512 threads (same pack as 1064)
     const long long wgs = (long long)a.N * ((a.GH + 3) / 4) * ((a.GW + 31) / 32) * (a.Cout / 64);
     if (on == 2 || wgs >= 1536) return 1064;
   }
   return 0;
 }
 
-void ssg_conv_halo_k32_tile(int fmt, int* th, int* tw) { *tw = 32; *th = fmt == 1128 ? 8 : 4; }
+void ssg_conv_halo_k32_tile(int fmt, int* th, int* tw) { *tw = 32; *th = fmt == 1128 ? 8 : (fmt == 2064 ? 16 : 4); }
 
 int ssg_conv_igemm_halo_k32_launch(const ConvArgs& a, int fmt, hipStream_t st) {
   if (fmt == 1128) return launch<8, 128, 4, 2>(a, st);
   if (fmt == 1064) return launch<4, 64, 2, 2>(a, st);
+  if (fmt == 2064) return launch<16, 64, 8, 1>(a, st);
   ssg_set_error("conv halo k32: unknown format %d", fmt);
   return SSG_EINVAL;
 }

@@ -215,6 +215,27 @@ Plan make_plan(const ssg_wgrad_desc* d) {
     p.mt = Cin / ssg_wgrad_halo_cb(p.variant);
     steps = (long long)d->N * d->GH * ((d->GW + BKP - 1) / BKP);
   }
+  if ((d->flags & 1) && ssg_wgrad_k32_ok(d)) {
+    // conv_wgrad_k32.hip: 512-thread workgroups (one per CU) on 9 x 64 x 64 tiles, a K-step = one image row of a 32-pixel column
+    // strip.  Slabs: as many as bring the grid to a whole number k of waves of 256 workgroups with the fewest empty CUs
+    // (k <= 4; at least 32 rows per slab)
+    p.halo = 2;
+    p.mt = Cin / 64; p.nt = d->Cout / 64;
+    steps = ssg_wgrad_k32_steps(d);
+    const long long tiles = (long long)p.mt * p.nt;
+    long long best = 1; double beff = 0;
+    for (int k = 1; k <= 4; ++k) {
+      long long sp = 256ll * k / tiles;
+      if (sp < 1) sp = 1;
+      if (sp > steps / 32) sp = steps / 32 > 0 ? steps / 32 : 1;
+      const long long wg = sp * tiles;
+      const double eff = (double)wg / (256.0 * ((wg + 255) / 256));
+      if (eff > beff + 0.02) { beff = eff; best = sp; }
+    }
+    p.steps_per_split = (int)((steps + best - 1) / best);
+    p.splits = (int)((steps + p.steps_per_split - 1) / p.steps_per_split);
+    return p;
+  }
   static const int wgs = [] { const char* e = getenv("SSG_WGRAD_WGS"); return e ? atoi(e) : 1024; }();
   long long want = wgs / ((long long)p.mt * p.nt);       // ~4 workgroups per CU overall (2048: +0.4 % slab traffic time)
   if (want < 1) want = 1;
@@ -306,7 +327,10 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
     if (rc != SSG_OK) return rc;
   } else {
     dim3 grid((unsigned)p.mt, (unsigned)p.nt, (unsigned)p.splits);
-    if (p.halo) {
+    if (p.halo == 2) {
+      rc = ssg_wgrad_k32_launch(a, grid, st);
+      if (rc != SSG_OK) return rc;
+    } else if (p.halo) {
       rc = ssg_wgrad_halo_launch(a, p.variant, grid, st, (d->flags & 1) != 0);
       if (rc != SSG_OK) return rc;
     } else if (wgrad_uses_dma(p.variant)) {
@@ -365,10 +389,11 @@ extern "C" int ssg_pack_weights_scaled_f32(const float* w_oihw, int O, int I, in
   return SSG_OK;
 }
 
-// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 30/31 = wgrad_halo<32,128>/<64,64>, 40/41 / 50/51 = the split-operand (x3) forms of 30/31 / 20/21, 15/16 = wgrad4 (4x4x1 MFMA)
+// which kernel a wgrad descriptor maps to: 0..2 = wgrad<128,128>/<128,64>/<128,32>, 20/21 = wgrad_dma<128,128>/<128,64>, 30/31 = wgrad_halo<32,128>/<64,64>, 40/41 / 50/51 = the split-operand (x3) forms of 30/31 / 20/21, 60 = wgrad_k32 (conv_wgrad_k32.hip), 15/16 = wgrad4 (4x4x1 MFMA)
 extern "C" int ssg_conv2d_wgrad_kernel_id(const ssg_wgrad_desc* d) {
   if (!d) return SSG_EINVAL;
   if (wgrad4_kind(d)) return 10 + wgrad4_kind(d);
+  if (make_plan(d).halo == 2) return 60;
   if (make_plan(d).halo) return ((d->flags & 1) ? 40 : 30) + make_plan(d).variant;
   const int v = make_plan(d).variant;
   return v + (wgrad_uses_dma(v) ? ((d->flags & 1) ? 50 : 20) : 0);

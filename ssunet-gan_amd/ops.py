@@ -240,7 +240,7 @@ _CONV_LABELS = {0: 'conv_igemm_kernel<128,128>', 1: 'conv_igemm_kernel<256,64>',
 _WGRAD_LABELS = {0: 'wgrad_kernel<128,128>', 1: 'wgrad_kernel<128,64>', 2: 'wgrad_kernel<128,32>',
                  20: 'wgrad_dma_kernel<128,128>', 21: 'wgrad_dma_kernel<128,64>',
                  30: 'wgrad_halo_kernel<32,128>', 31: 'wgrad_halo_kernel<64,64>',
-                 40: 'wgrad_halo_x3_kernel<32,128>', 41: 'wgrad_halo_x3_kernel<64,64>',
+                 40: 'wgrad_halo_x3_kernel<32,128>', 41: 'wgrad_halo_x3_kernel<64,64>', 60: 'wgrad_k32_kernel<64,64>',
                  50: 'wgrad_dma_x3_kernel<128,128>', 51: 'wgrad_dma_x3_kernel<128,64>',
                  15: 'wgrad4_kernel<thin_cout>', 16: 'wgrad4_kernel<thin_cin>', 17: 'wgrad_tiny4_kernel', 18: 'wgrad32_cin_kernel'}
 
@@ -298,7 +298,7 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     if MFMA_SPLIT and kmode == 0:      # decided first: the split-operand kernel has its own tile geometry (bnpart rows)
         bn = call('ssg_conv2d_split_bn', C.byref(d))
         if bn:
-            split = _split_pack(wpk, row0, cout, kp, bn)
+            split = _split_pack(wpk, row0, cout, kp, 1064 if bn == 2064 else bn)      # 2064: the 16-row tile reads the 64-column k32 pack
             d.w_split = split.data_ptr()
     part = None
     if want_bn and BN_EPILOGUE:
@@ -319,7 +319,7 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
         if parity_merge:
             label = 'conv_igemm_halo_x3_kernel<128,64,4,1,true>'
         elif split is not None and bn >= 1000:
-            label = 'conv_halo_k32_kernel<8,128>' if bn == 1128 else 'conv_halo_k32_kernel<4,64>'
+            label = {1128: 'conv_halo_k32_kernel<8,128>', 1064: 'conv_halo_k32_kernel<4,64>', 2064: 'conv_halo_k32_kernel<16,64>'}[bn]
         elif split is not None:
             if 'halo' in label:
                 label = label.replace('conv_igemm_halo_kernel', 'conv_igemm_halo_x3_kernel').replace('<256,64>', '<128,64>')

@@ -1,0 +1,34 @@
+"""Where a tile of conv_halo_k32_kernel spends its cycles: s_memtime stamps at kernel start / main-loop start / main-loop end / after
+the output stores, median over workgroups.  Needs the diagnostic build (no stamp executes in the product build):
+  cd ssunet-gan_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DSSG_K32_PROBE -c conv_igemm_halo_k32.hip -o /tmp/k32_probe.o
+  hipcc -shared -fPIC --offload-arch=gfx950 $(ls *.o | grep -v conv_igemm_halo_k32.o) /tmp/k32_probe.o -o ../libssunet_probe.so"""
+import ctypes as C
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('SSG_LIB_PATH', os.path.join(ROOT, 'ssunet-gan_amd', 'libssunet_probe.so'))
+sys.path.insert(0, ROOT)
+import torch
+import ssunet_gan_amd as S
+from ssunet_gan_amd import ops, _lib
+from ssunet_gan_amd._lib import ACT_NONE
+dev = 'cuda'
+lib = _lib.load()
+probe = torch.zeros(4 * 65536, dtype=torch.int64, device=dev)
+assert lib.ssg_debug_set_probe_buffer_k32(C.c_void_p(probe.data_ptr())) == 0
+ops.MFMA_SPLIT = True
+torch.manual_seed(0)
+for (ci, co, hw) in [(64, 64, 512), (192, 64, 512), (128, 128, 256), (512, 512, 32)]:
+    x = ops.to_nhwc(torch.randn(16, ci, hw, hw, device=dev)); w = torch.randn(co, ci, 3, 3, device=dev) / (3 * ci ** 0.5)
+    for _ in range(6):
+        y = ops._conv_fwd_impl(x, None, w, None, 1, 1, ACT_NONE, 0.0)
+    torch.cuda.synchronize()
+    probe.zero_()
+    y = ops._conv_fwd_impl(x, None, w, None, 1, 1, ACT_NONE, 0.0)
+    torch.cuda.synchronize()
+    p = probe.cpu().view(-1, 4)
+    p = p[p[:, 3] > 0].double()
+    d = lambda a, b: (p[:, b] - p[:, a]).median().item()
+    span = (p[:, 3].max() - p[:, 0].min()).item()
+    print('cin%d cout%d %dx%d: %d workgroups; per tile (median cycles): prologue %.0f, main loop %.0f (%.0f per step), epilogue + stores %.0f, total %.0f; '
+          'first start -> last end %.0f cycles' % (ci, co, hw, hw, p.shape[0], d(0, 1), d(1, 2), d(1, 2) / (ci // 32 * 9), d(2, 3), d(0, 3), span), flush=True)
