@@ -10,6 +10,7 @@
 #include "lds_dma.h"
 #include "conv_args.h"
 #include "mfma_split.h"
+#include "conv_slow.h"
 
 namespace {
 
@@ -140,6 +141,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_x3_kernel(const ConvArg
 #undef SSG_X3_TERM
   }
   wait_vmcnt<0>();
+  wait_lds_reads();
+  {                                                      // non-finite operands: conv_slow.h
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bad |= ssg_nonfinite16(acc[j]);
+    if (__builtin_amdgcn_readfirstlane(__syncthreads_or(bad))) {     // scalar condition: a uniform branch, the accumulators are dead inside it
+      const ConvArgs& as = *ssg_reload_args<ConvArgs>();
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        ssg_slow_refill16(acc[j], (float*)ldsb + tid, 256, [&](int r) {
+          const int p = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          return ssg_conv_slow_value(as, n, ty * TH + (p >> 4), tx * 16 + (p & 15), n0 + j * 32 + l31, 0, as.ntaps);
+        });
+    }
+  }
 
   // ---- epilogue of conv_igemm_dma.hip for a 4 x 1 wave layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool want_bn = a.bnpart != nullptr;

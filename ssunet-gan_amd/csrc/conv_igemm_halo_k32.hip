@@ -236,7 +236,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bad |= ssg_nonfinite(acc[i][j][r]);
-    if (__syncthreads_or(bad)) {                         // also: every wave has left the main loop, LDS is scratch
+    if (__builtin_amdgcn_readfirstlane(__syncthreads_or(bad))) {     // scalar condition: a uniform branch, the accumulators are dead inside it                         // also: every wave has left the main loop, LDS is scratch
       float* scr = (float*)lds + tid;                    // value e of this thread at scr[e * threads]
       // the argument block is re-read from the kernarg segment HERE (opaque pointer): kept live in SGPRs across the main loop for
       // this cold path, its fields spilled 6 registers of the hot loop

@@ -26,6 +26,7 @@
 #include "conv_args.h"
 #include "conv_halo_epilogue.h"
 #include "mfma_split.h"
+#include "conv_slow.h"
 
 namespace {
 
@@ -198,6 +199,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_halo_x3r_kernel(const ConvA
   }
   wait_vmcnt<0>();
   wait_lds_reads();
+  {                                                      // non-finite operands: conv_slow.h
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bad |= ssg_nonfinite16(acc[i][j]);
+    if (__builtin_amdgcn_readfirstlane(__syncthreads_or(bad))) {     // scalar condition: a uniform branch, the accumulators are dead inside it
+      const ConvArgs& as = *ssg_reload_args<ConvArgs>();
+      float* scr = (float*)lds + tid;
+#pragma unroll 1
+      for (int e = 0; e < MI * NI * 16; ++e) {
+        const int i = e / (NI * 16), j = (e >> 4) % NI, r = e & 15;
+        const int p = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        scr[e * 256] = ssg_conv_slow_value(as, n, ty * TH + (p >> TWL), tx * TW + (p & (TW - 1)), n0 + wn * WTN + j * 32 + l31, 0, 9);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = scr[((i * NI + j) * 16 + r) * 256];
+    }
+  }
   ssg_halo_epilogue<BM, BN, WAVES_M, WAVES_N, TWL, false>(a, acc, lds, n, ty, tx, n0, 0, wm, wn, half, l31);
 }
 
@@ -410,6 +434,49 @@ __global__ __launch_bounds__(256, (BN == 64 && !PARITY) ? 3 : 2) void conv_igemm
     ssg_probe_buf_x3[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - pr0;
   }
 #endif
+  {                                                      // non-finite operands: conv_slow.h
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < NCLS; ++q)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bad |= ssg_nonfinite16(acc[q][i][j]);
+    if (__builtin_amdgcn_readfirstlane(__syncthreads_or(bad))) {
+      const ConvArgs& as = *ssg_reload_args<ConvArgs>();
+      if constexpr (PARITY) {
+        // 128 accumulators per lane: the slow path writes the four classes itself (the merged launch has no bias, residual or
+        // statistics: ssg_conv_halo_x3_parity_ok) instead of refilling registers, which would spill
+#pragma unroll 1
+        for (int e = 0; e < 4 * MI * NI * 16; ++e) {
+          const int q = e / (MI * NI * 16), i = (e / (NI * 16)) % MI, j = (e >> 4) % NI, r = e & 15;
+          const int t_lo = q == 0 ? 0 : (q == 1 ? 1 : (q == 2 ? 3 : 5)), t_hi = q == 0 ? 1 : (q == 1 ? 3 : (q == 2 ? 5 : 9));   // taps of class q: 0 | 1 2 | 3 4 | 5..8
+          const int p = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int gy = ty * TH + (p >> TWL), gx = tx * TW + (p & (TW - 1)), co = n0 + wn * WTN + j * 32 + l31;
+          const int GHq = (as.OH - (q >> 1) + 1) >> 1, GWq = (as.OW - (q & 1) + 1) >> 1;
+          if (gy < GHq && gx < GWq && co < as.Cout) {
+            const float v = ssg_conv_slow_value(as, n, gy, gx, co, t_lo, t_hi);
+            as.out[((size_t)(n * as.OH + 2 * gy + (q >> 1)) * as.OW + 2 * gx + (q & 1)) * as.ldo + co] = ssg_act(v, as.act, as.slope);
+          }
+        }
+        return;
+      } else {
+        float* scr = (float*)lds + tid;                   // element e at scr[e * 256] (<= 64 elements = 64 KB)
+#pragma unroll 1
+        for (int e = 0; e < MI * NI * 16; ++e) {
+          const int i = e / (NI * 16), j = (e >> 4) % NI, r = e & 15;
+          const int p = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          scr[e * 256] = ssg_conv_slow_value(as, n, ty * TH + (p >> TWL), tx * TW + (p & (TW - 1)), n0 + wn * WTN + j * 32 + l31, 0, 9);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][i][j][r] = scr[((i * NI + j) * 16 + r) * 256];
+      }
+    }
+  }
   if constexpr (PARITY) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

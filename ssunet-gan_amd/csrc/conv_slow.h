@@ -10,6 +10,7 @@
 #pragma once
 #include "common.h"
 #include "conv_args.h"
+#include "conv_wgrad_args.h"
 
 __device__ __forceinline__ bool ssg_nonfinite(float v) { return !(__builtin_fabsf(v) <= 3.4028234663852886e38f); }
 
@@ -32,6 +33,83 @@ __device__ inline float ssg_conv_slow_value(const ConvArgs& a, int n, int gy, in
       acc = __builtin_fmaf(x[0], w[0], acc); acc = __builtin_fmaf(x[1], w[1], acc);
       acc = __builtin_fmaf(x[2], w[2], acc); acc = __builtin_fmaf(x[3], w[3], acc);
     }
+  }
+  return acc;
+}
+
+// Refill one 32x32 accumulator fragment (16 values per lane) on the slow path: `value(r)` computes element r; the values pass through
+// LDS scratch (`scr` = this thread's column: element r at scr[r * nthreads]) so that the loop over r stays a loop -- indexing the
+// accumulator registers dynamically would put them in scratch memory for the whole kernel.
+template <class F>
+__device__ __forceinline__ void ssg_slow_refill16(f32x16& acc, float* scr, int nthreads, F&& value) {
+#pragma unroll 1
+  for (int r = 0; r < 16; ++r) scr[r * nthreads] = value(r);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = scr[r * nthreads];
+}
+
+__device__ __forceinline__ bool ssg_nonfinite16(const f32x16& v) {
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bad |= ssg_nonfinite(v[r]);
+  return bad;
+}
+
+// the kernel's argument block, re-read from the kernarg segment at the point of use: its fields must not stay live in SGPRs across
+// the hot loop for the sake of this cold path (that spilled registers of the k32 kernel)
+template <class Args>
+__device__ __forceinline__ const Args* ssg_reload_args() {
+  const Args* ap = (const Args*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ap));
+  return ap;
+}
+
+template <class F>
+__device__ __forceinline__ void ssg_slow_refill4(f32x4& acc, float* scr, int nthreads, F&& value) {
+#pragma unroll 1
+  for (int r = 0; r < 4; ++r) scr[r * nthreads] = value(r);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = scr[r * nthreads];
+}
+
+// ---- weight gradients: one element dW[tap t][input channel c][output channel co] summed with fp32 FMAs over a workgroup's pixels
+__device__ __forceinline__ float ssg_wgrad_slow_pixel(const WgArgs& a, int dyt, int dxt, int c, int co, int n, int gy, int gx, float acc) {
+  const int iy = gy * a.in_sy + dyt, ix = gx * a.in_sx + dxt;
+  if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) return acc;
+  const size_t pix = (size_t)(n * a.H + iy) * a.W + ix;
+  const float x = c < a.C1 ? a.in1[pix * a.ld1 + c] : a.in2[pix * a.ld2 + (c - a.C1)];
+  return __builtin_fmaf(x, a.dout[((size_t)(n * a.GH + gy) * a.GW + gx) * a.ldd + co], acc);
+}
+
+// pixels P0 <= P < P1 of the flat N x GH x GW grid (wgrad_dma_x3_kernel's slabs)
+__device__ inline float ssg_wgrad_slow_value_flat(const WgArgs& a, int t, int c, int co, long long P0, long long P1) {
+  if (co >= a.Cout || c >= a.C1 + a.C2 || t >= a.ntaps) return 0.f;
+  const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
+  const int dyt = (tb & 7) - 2, dxt = (tb >> 3) - 2;
+  const long long GHW = (long long)a.GH * a.GW;
+  int n = (int)(P0 / GHW); const int rem = (int)(P0 - n * GHW);
+  int gy = rem / a.GW, gx = rem - gy * a.GW;
+  float acc = 0.f;
+  for (long long P = P0; P < P1; ++P) {
+    acc = ssg_wgrad_slow_pixel(a, dyt, dxt, c, co, n, gy, gx, acc);
+    if (++gx == a.GW) { gx = 0; if (++gy == a.GH) { gy = 0; ++n; } }
+  }
+  return acc;
+}
+
+// K-steps S0 <= S < S1 in column-strip order: S = (n * XB + strip) * GH + gy, a step = KPX pixels of row gy from column strip * KPX
+// (wgrad_halo_x3_kernel: KPX = 16; wgrad_k32_kernel: KPX = 32)
+__device__ inline float ssg_wgrad_slow_value_strips(const WgArgs& a, int t, int c, int co, long long S0, long long S1, int KPX) {
+  if (co >= a.Cout || c >= a.C1 + a.C2 || t >= a.ntaps) return 0.f;
+  const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
+  const int dyt = (tb & 7) - 2, dxt = (tb >> 3) - 2;
+  const int XB = (a.GW + KPX - 1) / KPX;
+  float acc = 0.f;
+  for (long long S = S0; S < S1; ++S) {
+    const int gy = (int)(S % a.GH); const long long col = S / a.GH;
+    const int xb = (int)(col % XB), n = (int)(col / XB);
+    const int gx1 = (xb + 1) * KPX < a.GW ? (xb + 1) * KPX : a.GW;
+    for (int gx = xb * KPX; gx < gx1; ++gx) acc = ssg_wgrad_slow_pixel(a, dyt, dxt, c, co, n, gy, gx, acc);
   }
   return acc;
 }

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "lds_dma.h"
 #include "conv_wgrad_args.h"
+#include "conv_slow.h"
 #include "mfma_split.h"
 
 namespace {
@@ -178,6 +179,28 @@ __device__ __forceinline__ void wgrad_dma_body(const WgArgs& a) {
     }
   }
 
+  if constexpr (X3) {                                    // non-finite operands: conv_slow.h
+    wait_lds_reads();
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bad |= ssg_nonfinite16(acc[i][j]);
+    if (__builtin_amdgcn_readfirstlane(__syncthreads_or(bad))) {     // scalar condition: a uniform branch, the accumulators are dead inside it
+      const WgArgs& as = *ssg_reload_args<WgArgs>();
+      const long long P0 = step0 * BKP, P1e = (step0 + nsteps) * BKP;
+      const long long P1 = P1e < as.Ptot ? P1e : as.Ptot;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          ssg_slow_refill16(acc[i][j], lds + tid, 256, [&](int r) {
+            const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int t = row / Cin;
+            return ssg_wgrad_slow_value_flat(as, t, row - t * Cin, n0 + wn * WTN + j * 32 + l31, P0, P1);
+          });
+    }
+  }
   float* slab = a.ws + (size_t)bz * a.M * a.Cout;
 #pragma unroll
   for (int i = 0; i < MI; ++i)

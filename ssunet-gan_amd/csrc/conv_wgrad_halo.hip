@@ -15,6 +15,7 @@
 #include "common.h"
 #include "lds_dma.h"
 #include "conv_wgrad_args.h"
+#include "conv_slow.h"
 
 namespace {
 
@@ -304,9 +305,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_x3_kernel(const WgArgs a) {
 #undef SSG_WX3
     }
   }
-
   float* slab = a.ws + (size_t)blockIdx.z * a.M * a.Cout;
   const int co = n0 + wn * 32 + l31;
+  {                                                      // non-finite operands: conv_slow.h
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) bad |= ssg_nonfinite16(acc[t]);
+    if (__builtin_amdgcn_readfirstlane(__syncthreads_or(bad))) {
+      // the slab values are written by the slow path itself (144 accumulators per lane: refilling them would spill)
+      const WgArgs& as = *ssg_reload_args<WgArgs>();
+#pragma unroll 1
+      for (int e = 0; e < 144; ++e) {
+        const int t = e >> 4, r = e & 15;
+        const int c = c0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float v = ssg_wgrad_slow_value_strips(as, t, c, co, step0, step0 + nsteps, BKP);
+        if (c < Cin && co < as.Cout) slab[((size_t)t * Cin + c) * as.Cout + co] = v;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll

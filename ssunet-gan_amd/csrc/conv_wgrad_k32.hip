@@ -18,6 +18,7 @@
 #include "lds_dma.h"
 #include "conv_wgrad_args.h"
 #include "mfma_split.h"
+#include "conv_slow.h"
 #include <stdlib.h>
 
 namespace {
@@ -214,6 +215,27 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int j = 0; j < 2; ++j) tot[t][j] += acc[t][j];
+
+  wait_lds_reads();
+  {                                                      // non-finite operands: conv_slow.h
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad |= ssg_nonfinite(tot[t][j][r]);
+    if (__builtin_amdgcn_readfirstlane(__syncthreads_or(bad))) {     // scalar condition: a uniform branch, the accumulators are dead inside it
+      const WgArgs& as = *ssg_reload_args<WgArgs>();
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          ssg_slow_refill4(tot[t][j], (float*)lds + tid, 512, [&](int r) {
+            return ssg_wgrad_slow_value_strips(as, t, c0 + wm * 16 + l15, n0 + (2 * wn + j) * 16 + 4 * g + r, S0, S1, KP);
+          });
+    }
+  }
 
   // ---- slab [split][row = tap * Cin + ci][Cout]: acc[tap][j][r] = (ci = c0 + wm*16 + l15, co = n0 + (2wn + j)*16 + 4g + r)
   float* slab = a.ws + (size_t)blockIdx.z * a.M * a.Cout;

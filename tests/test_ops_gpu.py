@@ -108,15 +108,35 @@ def _split_label(name):
     return name
 
 
-@pytest.mark.parametrize('split', [True, False], ids=['split', 'fp32mfma'])
+def _k32_label(name, cin, cout, w):
+    """Label of the round-4 32-channel-chunk kernel (csrc/conv_igemm_halo_k32.hip, conv_wgrad_k32.hip) that takes the launch when it
+    is forced on (ssg_conv_set_k32_mode(2) / ssg_wgrad_set_k32_mode(1)), or None where the shape is not eligible."""
+    if name.startswith('conv_igemm_halo_kernel<') and '+splitk' not in name and w >= 17:
+        return 'conv_halo_k32_kernel<'                      # any of its three tiles: which one depends on the grid
+    if name.startswith('wgrad_halo_kernel<') and cin % 64 == 0 and cout % 64 == 0 and w >= 17:
+        return 'wgrad_k32_kernel<64,64>'
+    return None
+
+
+@pytest.mark.parametrize('split', ['x3', 'fp32mfma', 'k32'])
 @pytest.mark.parametrize('case', KERNEL_CASES)
 def test_conv2d_specialised_kernels(pkg, dev, case, split, monkeypatch):
     n, cin, cout, h, w, k, p, expect = case
-    if split:
+    family, split = split, split != 'fp32mfma'
+    if family == 'x3':
         if not any(_split_label(e) != e for e in expect):
             pytest.skip('no split-operand kernel on this case')
         # the split conv kernels take whole 64 / 128-column tiles (other Cout stay on the fp32 MFMA); the weight gradient always splits
         expect = tuple(_split_label(e) if (cout % 64 == 0 or e.startswith('wgrad')) else e for e in expect)
+    elif family == 'k32':
+        # forward: Cin % 32 and Cout % 64; the input gradient swaps the two; both must hold for every halo label to move
+        swap = [_k32_label(e, cin, cout, w) for e in expect]
+        ok_conv = cin % 64 == 0 and cout % 64 == 0
+        if not any(swap) or not ok_conv:
+            pytest.skip('no k32 kernel on this case')
+        expect = tuple(sw if sw else _split_label(e) for e, sw in zip(expect, swap))
+    pkg._lib.call('ssg_conv_set_k32_mode', 2 if family == 'k32' else 0)
+    pkg._lib.call('ssg_wgrad_set_k32_mode', 1 if family == 'k32' else 0)
     monkeypatch.setattr(pkg.ops, 'MFMA_SPLIT', split)      # restored on every exit path (ADVICE r3)
     g = torch.Generator().manual_seed(1234 + cin + cout)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -140,8 +160,9 @@ def test_conv2d_specialised_kernels(pkg, dev, case, split, monkeypatch):
         labels = [rec[0] for rec in pkg.ops.PROFILE]
     finally:
         pkg.ops.PROFILE = None
+        pkg._lib.call('ssg_conv_set_k32_mode', 1); pkg._lib.call('ssg_wgrad_set_k32_mode', 1)
     for name in expect:
-        assert name in labels, '%s did not run (ran: %s)' % (name, labels)
+        assert any(l == name or (name.endswith('<') and l.startswith(name)) for l in labels), '%s did not run (ran: %s)' % (name, labels)
     _close(yd, yr, 1e-5, 2e-6 * math.sqrt(cin * k * k), 'fwd')
     _close(d[0].grad, ref[0].grad, 1e-5, 2e-6 * math.sqrt(cout * k * k), 'dgrad')
     _close(d[1].grad, ref[1].grad, 2e-5, 2e-6 * math.sqrt(n * h * w), 'wgrad')
@@ -249,7 +270,7 @@ def test_conv2d_concat_halo(pkg, dev):
     finally:
         pkg.ops.PROFILE = None
     assert any(l.startswith(('conv_igemm_halo_kernel<128,64>', 'conv_igemm_halo_x3_kernel<128,64>')) for l in labels), labels
-    assert ('wgrad_halo_x3_kernel<32,128>' if pkg.ops.MFMA_SPLIT else 'wgrad_halo_kernel<32,128>') in labels, labels
+    assert any(l in labels for l in (('wgrad_k32_kernel<64,64>', 'wgrad_halo_x3_kernel<32,128>') if pkg.ops.MFMA_SPLIT else ('wgrad_halo_kernel<32,128>',))), labels
     _close(yd, yr, 1e-5, 7e-5, 'concat halo conv')
     for a, b, nm in zip(d, r, ('dx1', 'dx2', 'dw')):
         _close(a.grad, b.grad, 2e-5, 7e-5, nm)

@@ -18,8 +18,20 @@ def _run(ops, split, fn):
         ops.MFMA_SPLIT = old
 
 
+@pytest.fixture(params=['x3', 'k32'])
+def family(request, pkg):
+    """Both split-operand families meet the same bounds: the 16-channel-chunk x3 kernels on v_mfma_f32_32x32x16_bf16 and the round-4
+    k32 kernels on v_mfma_f32_16x16x32_bf16 (forced on: at these sizes the default dispatch keeps most launches on x3)."""
+    k32 = request.param == 'k32'
+    pkg._lib.call('ssg_conv_set_k32_mode', 2 if k32 else 0)
+    pkg._lib.call('ssg_wgrad_set_k32_mode', 1 if k32 else 0)
+    yield request.param
+    pkg._lib.call('ssg_conv_set_k32_mode', 1)
+    pkg._lib.call('ssg_wgrad_set_k32_mode', 1)
+
+
 @pytest.mark.parametrize('c1,c2,co,hw,nb', [(128, 0, 128, 128, 6), (64, 0, 64, 128, 4), (64, 128, 64, 128, 4), (128, 256, 128, 128, 6), (256, 0, 384, 64, 8)])
-def test_split_conv_matches_fp64_like_fp32_mfma(pkg, dev, c1, c2, co, hw, nb):
+def test_split_conv_matches_fp64_like_fp32_mfma(pkg, dev, c1, c2, co, hw, nb, family):
     ops = pkg.ops
     torch.manual_seed(21)
     torch.set_num_threads(16)
@@ -39,7 +51,7 @@ def test_split_conv_matches_fp64_like_fp32_mfma(pkg, dev, c1, c2, co, hw, nb):
         labels = [p[0] for p in ops.PROFILE]
     finally:
         ops.PROFILE = None
-    assert labels and 'halo_x3' in labels[0], 'the split kernel did not run: %s' % labels
+    assert labels and ('halo_x3' if family == 'x3' else 'halo_k32') in labels[0], 'the %s kernel did not run: %s' % (family, labels)
     e32 = (y32 - ref).abs(); e3 = (y3 - ref).abs()
     assert e3.max().item() <= 2.0 * e32.max().item() + 1e-6, (e3.max().item(), e32.max().item())
     assert e3.pow(2).mean().sqrt().item() <= 2.0 * e32.pow(2).mean().sqrt().item() + 1e-8
@@ -66,7 +78,7 @@ def test_split_conv_matches_fp64_like_fp32_mfma(pkg, dev, c1, c2, co, hw, nb):
         wl = [p[0] for p in ops.PROFILE]
     finally:
         ops.PROFILE = None
-    assert wl and 'wgrad_halo_x3' in wl[0], 'the split weight-gradient kernel did not run: %s' % wl
+    assert wl and ('wgrad_halo_x3' if family == 'x3' else 'wgrad_k32') in wl[0], 'the %s weight-gradient kernel did not run: %s' % (family, wl)
     ew32 = (w32 - wref).abs(); ew3 = (w3 - wref).abs()
     assert ew3.max().item() <= 2.0 * ew32.max().item() + 1e-6 * wref.abs().max().item(), (ew3.max().item(), ew32.max().item())
     assert ew3.pow(2).mean().sqrt().item() <= 2.0 * ew32.pow(2).mean().sqrt().item() + 1e-8
@@ -223,3 +235,124 @@ def test_merged_parity_declines_narrow_images(pkg, dev):
         ops.PROFILE = None
     assert len(labels) == 4 and not any('true' in l for l in labels), labels
     assert (g - gref).abs().max().item() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# non-finite and extreme operands.  x = x1 + x2 + x3 in bf16 terms turns +-inf into (inf, NaN, NaN) and a finite
+# |x| above the bf16 maximum (3.3895e38) into (inf, -inf, NaN), where the fp32 kernels -- and the reference: losses.py:297-300 keys
+# on inf vs NaN, train_seg_gan.py:190 zeroes NaN only -- keep +-inf / a finite product.  The split kernels detect such operands
+# (every accumulator they touch is non-finite) and recompute the affected workgroup's tile with plain fp32 FMAs (csrc/conv_slow.h):
+# the result must be of the fp32-MFMA kernel's CLASS element by element (finite / +inf / -inf / NaN) and equal where finite.
+SPECIALS = [float('inf'), float('-inf'), float('nan'), 3.4e38, -3.4e38, 1e-40, 1e30, -1e30, 1e-30]
+
+
+def _inject(t, specials, seed, dim=1):
+    """One special value per DISTINCT channel (dim 1) at a random position: an output sees at most one of them per operand."""
+    g = torch.Generator().manual_seed(seed)
+    t = t.clone()
+    chans = torch.randperm(t.shape[dim], generator=g)[:len(specials)]
+    for v, c in zip(specials, chans):
+        idx = [int(torch.randint(0, s, (1,), generator=g)) for s in t.shape]
+        idx[dim] = int(c)
+        t[tuple(idx)] = v
+    return t
+
+
+def _same_class(got, want, what, rtol=2e-5):
+    got = got.detach().cpu().double(); want = want.detach().cpu().double()
+    for name, f in (('NaN', torch.isnan), ('+inf', lambda t: torch.isposinf(t)), ('-inf', lambda t: torch.isneginf(t))):
+        a, b = f(got), f(want)
+        assert torch.equal(a, b), '%s: %s pattern differs from the fp32-MFMA kernel at %d elements (%d vs %d)' % (what, name, int((a != b).sum()), int(a.sum()), int(b.sum()))
+    fin = torch.isfinite(want)
+    assert int((~fin).sum()) > 0, '%s: the test operands produced no non-finite output' % what
+    d = (got[fin] - want[fin]).abs()
+    # sums that hold a 1e30-class term are compared relative to it; everything else to the usual fp32 accumulation noise
+    tol = rtol * want[fin].abs() + 2e-4
+    assert bool((d <= tol).all()), '%s: finite elements differ, worst %.3e (value %.3e)' % (what, (d - tol).max().item(), want[fin][(d - tol).argmax()].item())
+
+
+def _labels(ops, fn):
+    ops.PROFILE = []
+    try:
+        r = fn()
+        torch.cuda.synchronize()
+        return r, [p[0] for p in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+
+
+@pytest.mark.parametrize('k32', [0, 2], ids=['x3', 'k32'])
+@pytest.mark.parametrize('c1,c2,co,h,w,nb', [(128, 0, 128, 64, 64, 2), (64, 64, 64, 48, 80, 2), (64, 0, 64, 64, 64, 3)])
+def test_split_conv_on_nonfinite_operands(pkg, dev, c1, c2, co, h, w, nb, k32):
+    ops = pkg.ops
+    call = pkg._lib.call
+    torch.manual_seed(5)
+    ci = c1 + c2
+    xc = _inject(torch.randn(nb, ci, h, w) * 1.5 + 0.3, SPECIALS, 11)
+    wc = torch.randn(co, ci, 3, 3) / (3 * ci ** 0.5)
+    wc_bad = _inject(wc, [float('inf'), float('nan'), 1e30, 1e-40, float('-inf')], 12, dim=0)
+    dyc = _inject(torch.randn(nb, co, h, w), SPECIALS, 13)
+    x1 = ops.to_nhwc(xc[:, :c1].to(dev)); x2 = ops.to_nhwc(xc[:, c1:].to(dev)) if c2 else None
+    xgc = torch.randn(nb, ci, h, w) * 1.5 + 0.3
+    xg1 = ops.to_nhwc(xgc[:, :c1].to(dev)); xg2 = ops.to_nhwc(xgc[:, c1:].to(dev)) if c2 else None
+    dy = ops.to_nhwc(dyc.to(dev))
+    call('ssg_conv_set_k32_mode', k32)
+    try:
+        want_label = 'k32' if k32 else 'halo_x3'
+        for what, fn in (
+                ('forward, special activations', lambda: ops._conv_fwd_impl(x1, x2, wc.to(dev), None, 1, 1, 0, 0.0)),
+                ('forward, special weights', lambda: ops._conv_fwd_impl(xg1, xg2, wc_bad.to(dev), None, 1, 1, 0, 0.0)),
+                ('input gradient, special dy', lambda: ops._conv_dgrad_impl(dy, wc.to(dev), 1, 1, h, w, 0, ci))):
+            want = _run(ops, False, fn)
+            got, labels = _labels(ops, lambda: _run(ops, True, fn))
+            assert any(want_label in l for l in labels), '%s: %s kernel did not run: %s' % (what, want_label, labels)
+            _same_class(got, want, '%s [%s]' % (what, labels[0]))
+    finally:
+        call('ssg_conv_set_k32_mode', 1)
+
+
+@pytest.mark.parametrize('cin,co,hw,k,stride', [(128, 128, 64, 3, 2), (128, 64, 64, 1, 1)])
+def test_split_dma_family_on_nonfinite_operands(pkg, dev, cin, co, hw, k, stride):
+    """1x1 and stride-2 convs (conv_igemm_dma_x3), the merged-parity input gradient of the stride-2 conv, and their weight gradient
+    (wgrad_dma_x3)."""
+    ops = pkg.ops
+    torch.manual_seed(6)
+    nb, pad = 2, k // 2
+    xc = _inject(torch.randn(nb, cin, hw, hw) * 1.5 + 0.3, SPECIALS, 21)
+    wc = torch.randn(co, cin, k, k) / (k * cin ** 0.5)
+    oh = (hw + 2 * pad - k) // stride + 1
+    dyc = _inject(torch.randn(nb, co, oh, oh), SPECIALS, 23)
+    x = ops.to_nhwc(xc.to(dev)); w = wc.to(dev); dy = ops.to_nhwc(dyc.to(dev))
+    xg = ops.to_nhwc((torch.randn(nb, cin, hw, hw) * 1.5 + 0.3).to(dev))
+    for what, fn, lab in (
+            ('forward', lambda: ops._conv_fwd_impl(x, None, w, None, stride, pad, 0, 0.0), 'dma_x3'),
+            ('input gradient', lambda: ops._conv_dgrad_impl(dy, w, stride, pad, hw, hw, 0, cin), 'x3'),
+            ('weight gradient, special dy', lambda: ops._conv_wgrad_impl(xg, None, dy, tuple(wc.shape), stride, pad), 'wgrad_dma_x3'),
+            ('weight gradient, special x', lambda: ops._conv_wgrad_impl(x, None, ops.to_nhwc(torch.randn(nb, co, oh, oh).to(dev)), tuple(wc.shape), stride, pad), 'wgrad_dma_x3')):
+        want = _run(ops, False, fn)
+        got, labels = _labels(ops, lambda: _run(ops, True, fn))
+        assert any(lab in l for l in labels), '%s: no %s kernel ran: %s' % (what, lab, labels)
+        _same_class(got, want, '%s [%s]' % (what, labels))
+
+
+@pytest.mark.parametrize('k32', [0, 1], ids=['halo_x3', 'k32'])
+@pytest.mark.parametrize('c1,c2,co,h,w,nb', [(64, 0, 64, 48, 64, 2), (128, 64, 128, 33, 40, 2)])
+def test_split_wgrad_on_nonfinite_operands(pkg, dev, c1, c2, co, h, w, nb, k32):
+    ops = pkg.ops
+    call = pkg._lib.call
+    torch.manual_seed(7)
+    ci = c1 + c2
+    xc = torch.randn(nb, ci, h, w) * 1.5 + 0.3
+    dyc = torch.randn(nb, co, h, w)
+    call('ssg_wgrad_set_k32_mode', k32)
+    try:
+        for what, xs, ds in (('special x', _inject(xc, SPECIALS, 31), dyc), ('special dy', xc, _inject(dyc, SPECIALS, 32))):
+            x1 = ops.to_nhwc(xs[:, :c1].to(dev)); x2 = ops.to_nhwc(xs[:, c1:].to(dev)) if c2 else None
+            dy = ops.to_nhwc(ds.to(dev))
+            fn = lambda: ops._conv_wgrad_impl(x1, x2, dy, (co, ci, 3, 3), 1, 1)
+            want = _run(ops, False, fn)
+            got, labels = _labels(ops, lambda: _run(ops, True, fn))
+            assert any(('wgrad_k32' if k32 else 'wgrad_halo_x3') in l for l in labels), labels
+            _same_class(got, want, 'weight gradient, %s [%s]' % (what, labels))
+    finally:
+        call('ssg_wgrad_set_k32_mode', 1)
