@@ -25,10 +25,13 @@ __device__ inline float ssg_conv_slow_value(const ConvArgs& a, int n, int gy, in
   for (int t = t_lo; t < t_hi; ++t) {
     const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
     const int iy = gy * a.in_sy + (tb & 7) - 2, ix = gx * a.in_sx + (tb >> 3) - 2;
-    if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) continue;
-    const size_t pix = (size_t)(n * a.H + iy) * a.W + ix;
+    // a tap outside the image multiplies ZEROS, it is not skipped: 0 * inf = NaN is what the zero padding of the fp32 kernels (and
+    // of F.conv2d) produces under a non-finite weight
+    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    const size_t pix = inside ? (size_t)(n * a.H + iy) * a.W + ix : 0;
     for (int c = 0; c < Cin; c += 4) {
-      const f32x4 x = c < a.C1 ? *(const f32x4*)(a.in1 + pix * a.ld1 + c) : *(const f32x4*)(a.in2 + pix * a.ld2 + (c - a.C1));
+      f32x4 x = c < a.C1 ? *(const f32x4*)(a.in1 + pix * a.ld1 + c) : *(const f32x4*)(a.in2 + pix * a.ld2 + (c - a.C1));
+      if (!inside) x = f32x4{0.f, 0.f, 0.f, 0.f};
       const f32x4 w = *(const f32x4*)(wrow + ((c >> 4) * a.ntaps + t) * 16 + (c & 15));
       acc = __builtin_fmaf(x[0], w[0], acc); acc = __builtin_fmaf(x[1], w[1], acc);
       acc = __builtin_fmaf(x[2], w[2], acc); acc = __builtin_fmaf(x[3], w[3], acc);
@@ -75,9 +78,10 @@ __device__ __forceinline__ void ssg_slow_refill4(f32x4& acc, float* scr, int nth
 // ---- weight gradients: one element dW[tap t][input channel c][output channel co] summed with fp32 FMAs over a workgroup's pixels
 __device__ __forceinline__ float ssg_wgrad_slow_pixel(const WgArgs& a, int dyt, int dxt, int c, int co, int n, int gy, int gx, float acc) {
   const int iy = gy * a.in_sy + dyt, ix = gx * a.in_sx + dxt;
-  if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) return acc;
-  const size_t pix = (size_t)(n * a.H + iy) * a.W + ix;
-  const float x = c < a.C1 ? a.in1[pix * a.ld1 + c] : a.in2[pix * a.ld2 + (c - a.C1)];
+  const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;      // outside: a ZERO times dy (0 * inf = NaN, as the zero page of the fp32 kernels)
+  const size_t pix = inside ? (size_t)(n * a.H + iy) * a.W + ix : 0;
+  float x = c < a.C1 ? a.in1[pix * a.ld1 + c] : a.in2[pix * a.ld2 + (c - a.C1)];
+  if (!inside) x = 0.f;
   return __builtin_fmaf(x, a.dout[((size_t)(n * a.GH + gy) * a.GW + gx) * a.ldd + co], acc);
 }
 

@@ -128,10 +128,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
       doff[j][t] = p * 128 + ((((2 * (2 * wn + j) + (pp >> 1)) ^ sw(p))) << 4) + (pp & 1) * 8;
   }
 
-  // acc takes FLUSH rows (1024 pixels) of MFMA accumulation, then is added into tot by the vector unit: the length of an fp32
-  // accumulation chain -- what the rounding error of a slab grows with -- stays that of wgrad_halo_x3's slabs however long this
-  // workgroup's slab is (one workgroup per CU makes for few, long slabs)
-  constexpr int FLUSH = 32;
+  // acc takes FLUSH rows (256 pixels) of MFMA accumulation, then is added into tot by the vector unit: the length of an fp32
+  // accumulation chain -- what the rounding error of a slab grows with -- stays that of the shortest slabs of the fp32-MFMA
+  // weight-gradient kernels (16 K-steps of 16 pixels) however long this workgroup's slab is (one workgroup per CU makes for few,
+  // long slabs; with 1024-pixel chains the rms error against fp64 was 2.06x the fp32-MFMA kernel's on a 64 -> 64 layer)
+  constexpr int FLUSH = 8;
   f32x4 acc[9][2], tot[9][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
