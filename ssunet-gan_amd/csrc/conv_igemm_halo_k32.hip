@@ -193,8 +193,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
-      issue_b(s + 2);
-      if (t == LD_T) load_px(chunk + 1);
+#ifndef SSG_K32_DMA_MID
+#define SSG_K32_DMA_MID 1                                  // 1: the step's DMA / pixel loads are issued in the middle of its MFMA stream (A/B build switch)
+#endif
+      constexpr bool MID = SSG_K32_DMA_MID && TH != 16;   // <16, 64> keeps them at the top: pinned mid-stream, its ten pixel loads per lane spill 15-23 registers
+      if constexpr (!MID) {
+        issue_b(s + 2);
+        if (t == LD_T) load_px(chunk + 1);
+      }
 
       const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
       const int toff = (((tb & 7) - 2) * HW + ((tb >> 3) - 2)) * 16;
@@ -213,12 +219,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                  \
   _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                  \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][QW], p[i][QP], acc[i][j], 0, 0, 0);
-      SSG_K32_TERM(2, 0) SSG_K32_TERM(1, 1) SSG_K32_TERM(0, 2)
+      SSG_K32_TERM(2, 0) SSG_K32_TERM(1, 1)
+      if constexpr (MID) {
+        // Right after the barrier all eight waves issue their fragment reads at once; an LDS-DMA instruction issued into that burst
+        // costs 100-185 cycles, among MFMAs ~60 (MI355X_MICROARCH.md): the pieces of step s + 2 go out after a third of the MFMAs
+        // (same-box A/B, 16 images: 240.9 / 260.6 / 273.1 -> 250.8 / 267.4 / 281.8 TFLOP/s on 128 -> 128 at 256^2 / 256 -> 256 at 128^2 / 384 -> 384 at 64^2)
+        __builtin_amdgcn_sched_barrier(0);
+        issue_b(s + 2);
+        if (t == LD_T) load_px(chunk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      SSG_K32_TERM(0, 2)
       SSG_K32_TERM(1, 0) SSG_K32_TERM(0, 1)
       SSG_K32_TERM(0, 0)
 #undef SSG_K32_TERM
       if (t == 8) {                                      // the loads of LD_T landed before tap 7's barrier
-        __builtin_amdgcn_sched_barrier(0);               // after the last MFMA is issued: the fragments are dead, no extra register pressure
+#ifndef SSG_K32_CVT_FREE
+#define SSG_K32_CVT_FREE 1
+#endif
+        // <8, 128> lets the scheduler weave the ~130 conversion instructions into tap 8's MFMAs (they fit its registers); the other
+        // two tiles pin them behind the last MFMA, where the fragments are dead (woven in, <4, 64> spilled 3 registers)
+        if (!(SSG_K32_CVT_FREE && TH == 8)) __builtin_amdgcn_sched_barrier(0);
         convert_px();
       }
     }

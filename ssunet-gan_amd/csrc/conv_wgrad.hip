@@ -216,21 +216,24 @@ Plan make_plan(const ssg_wgrad_desc* d) {
     steps = (long long)d->N * d->GH * ((d->GW + BKP - 1) / BKP);
   }
   if ((d->flags & 1) && ssg_wgrad_k32_ok(d)) {
-    // conv_wgrad_k32.hip: 512-thread workgroups (one per CU) on 9 x 64 x 64 tiles, a K-step = one image row of a 32-pixel column
-    // strip.  Slabs: as many as bring the grid to a whole number k of waves of 256 workgroups with the fewest empty CUs
-    // (k <= 4; at least 32 rows per slab)
+    // conv_wgrad_k32.hip: 512-thread workgroups (one per CU) on 9 x 64 x 64 tiles, a K-step = one image row of a 32-pixel column strip
     p.halo = 2;
     p.mt = Cin / 64; p.nt = d->Cout / 64;
     steps = ssg_wgrad_k32_steps(d);
     const long long tiles = (long long)p.mt * p.nt;
-    long long best = 1; double beff = 0;
-    for (int k = 1; k <= 4; ++k) {
-      long long sp = 256ll * k / tiles;
-      if (sp < 1) sp = 1;
-      if (sp > steps / 32) sp = steps / 32 > 0 ? steps / 32 : 1;
+    // Slabs: a slab is one workgroup's accumulation chain, so its length bounds the fp32 rounding error -- at most 128 rows (4096
+    // pixels, the slab of wgrad_halo_x3 at the bench sizes; in-register totals that cut the chain instead cost 72 registers and
+    // 10 % of the kernel: DESIGN.md 3.10) and at least 8 rows (256 pixels, the shortest slab of the fp32 kernels); within that,
+    // the count that leaves the fewest CUs idle in the last wave of 256 workgroups (one workgroup per CU)
+    const long long lo = ssg_wgrad_k32_flush() == 0 ? (steps + 127) / 128 : 1;
+    long long hi = steps / 8;
+    if (hi < lo) hi = lo;
+    long long best = lo; double beff = 0;
+    for (long long sp = lo; sp <= hi && sp <= lo + 1024; ++sp) {
       const long long wg = sp * tiles;
       const double eff = (double)wg / (256.0 * ((wg + 255) / 256));
-      if (eff > beff + 0.02) { beff = eff; best = sp; }
+      if (eff > beff + 1e-9) { beff = eff; best = sp; }
+      if (eff >= 0.97 && wg >= 256) break;
     }
     p.steps_per_split = (int)((steps + best - 1) / best);
     p.splits = (int)((steps + p.steps_per_split - 1) / p.steps_per_split);

@@ -25,4 +25,5 @@ int ssg_wgrad_halo_launch(const WgArgs& a, int variant, dim3 grid, hipStream_t s
 // conv_wgrad_k32.hip (round 4): split operands on v_mfma_f32_16x16x32_bf16, 9 x 64 x 64 tiles of 512 threads, rolling 3-row window
 bool ssg_wgrad_k32_ok(const ssg_wgrad_desc* d);
 long long ssg_wgrad_k32_steps(const ssg_wgrad_desc* d);
+int ssg_wgrad_k32_flush();                                 // rows per in-register flush (0: none -- slabs then stay <= 128 rows)
 int ssg_wgrad_k32_launch(const WgArgs& a, dim3 grid, hipStream_t st);

@@ -37,6 +37,10 @@ constexpr int DSLOT = KP * 128;
 constexpr int DPLANE = 2 * DSLOT;
 constexpr int DIMG = 3 * DPLANE;
 constexpr int CB = 64, BN = 64;
+#ifndef SSG_WK32_FLUSH
+#define SSG_WK32_FLUSH 0                       // > 0: rows of MFMA accumulation per flush into vector-unit totals (A/B; costs 72 registers and ~10 %); 0: the slab
+                                               // length bounds the accumulation chain instead (conv_wgrad.hip: at most 128 rows per slab)
+#endif
 
 // 16-byte chunk c (0..7) of pixel row p sits at chunk position c ^ sw(p)
 __device__ __forceinline__ int sw(int p) { return ((((p >> 1) & 1) | (((p >> 3) & 1) << 1)) << 1); }
@@ -128,11 +132,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
       doff[j][t] = p * 128 + ((((2 * (2 * wn + j) + (pp >> 1)) ^ sw(p))) << 4) + (pp & 1) * 8;
   }
 
-  // acc takes FLUSH rows (256 pixels) of MFMA accumulation, then is added into tot by the vector unit: the length of an fp32
-  // accumulation chain -- what the rounding error of a slab grows with -- stays that of the shortest slabs of the fp32-MFMA
-  // weight-gradient kernels (16 K-steps of 16 pixels) however long this workgroup's slab is (one workgroup per CU makes for few,
-  // long slabs; with 1024-pixel chains the rms error against fp64 was 2.06x the fp32-MFMA kernel's on a 64 -> 64 layer)
-  constexpr int FLUSH = 8;
+  // Accumulation chains: the rounding error of a slab grows with the number of pixels one accumulator sums.  Default: the planner keeps
+  // a slab at <= 128 rows (4096 pixels, wgrad_halo_x3's slab at the bench sizes; rms error vs fp64 then equals that kernel's).  With
+  // FLUSH > 0 acc takes FLUSH rows and is then added into tot by the vector unit (slabs may be long): measured 205 vs 228 TFLOP/s.
+  constexpr int FLUSH = SSG_WK32_FLUSH;
   f32x4 acc[9][2], tot[9][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
         store_x(nx, (gy + 3) & 3);                       // row gy + 2
         store_d(nd, (gy + 1) & 1);
       }
-      if (++since == FLUSH) {
+      if (FLUSH > 0 && ++since == FLUSH) {
         since = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -271,6 +274,8 @@ bool ssg_wgrad_k32_ok(const ssg_wgrad_desc* d) {
   const unsigned long long db = (unsigned long long)d->N * d->GH * d->GW * (unsigned long long)d->ldd * 4ull;
   return xb <= 0xfffffff0ull && db <= 0xfffffff0ull;
 }
+
+int ssg_wgrad_k32_flush() { return SSG_WK32_FLUSH; }
 
 // K-steps of the k32 kernel: one per image row of each 32-pixel column strip
 long long ssg_wgrad_k32_steps(const ssg_wgrad_desc* d) { return (long long)d->N * ((d->GW + KP - 1) / KP) * d->GH; }
