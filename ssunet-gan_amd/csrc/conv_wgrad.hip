@@ -225,7 +225,21 @@ Plan make_plan(const ssg_wgrad_desc* d) {
     // pixels, the slab of wgrad_halo_x3 at the bench sizes; in-register totals that cut the chain instead cost 72 registers and
     // 10 % of the kernel: DESIGN.md 3.10) and at least 8 rows (256 pixels, the shortest slab of the fp32 kernels); within that,
     // the count that leaves the fewest CUs idle in the last wave of 256 workgroups (one workgroup per CU)
-    const long long lo = ssg_wgrad_k32_flush() == 0 ? (steps + 127) / 128 : 1;
+    // ... and never longer than the chain the 16-pixel-step kernels would use on this shape (their planner below: ~1024 workgroups,
+    // >= 16 steps per slab), so that the rounding error of the two families stays equal on every shape, not only at the bench sizes
+    long long max_rows = 128;
+    {
+      const long long steps16 = (long long)d->N * d->GH * ((d->GW + BKP - 1) / BKP);
+      const long long mtf = Cin / ssg_wgrad_halo_cb(p.variant), ntf = (d->Cout + (p.variant == 0 ? 127 : 63)) / (p.variant == 0 ? 128 : 64);
+      long long wantf = 1024 / (mtf * ntf > 0 ? mtf * ntf : 1);
+      if (wantf < 1) wantf = 1;
+      if (wantf > steps16 / 16) wantf = steps16 / 16 > 0 ? steps16 / 16 : 1;
+      if (wantf > 512) wantf = 512;
+      const long long chain_px = (steps16 + wantf - 1) / wantf * BKP;
+      if (chain_px / 32 < max_rows) max_rows = chain_px / 32;
+      if (max_rows < 8) max_rows = 8;
+    }
+    const long long lo = ssg_wgrad_k32_flush() == 0 ? (steps + max_rows - 1) / max_rows : 1;
     long long hi = steps / 8;
     if (hi < lo) hi = lo;
     long long best = lo; double beff = 0;
