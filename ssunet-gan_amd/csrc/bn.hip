@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
   constexpr int Q = SsgQ<T>::value;          // channel quads per 16-byte access
   const int CG = C / (4 * Q);
   const long long total = P * CG;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+  SSG_CHUNK_LOOP(i, total) {
     const long long p = i / CG; const int c0 = 4 * Q * (int)(i - p * CG);
     f32x4 xv[Q], rv[Q], o[Q];
     ldq(x + p * ld + c0, xv);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   constexpr int Q = SsgQ<T>::value;
   const int CG = C / (4 * Q);
   const long long totalg = P * CG;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < totalg; i += (long long)gridDim.x * 256) {
+  SSG_CHUNK_LOOP(i, totalg) {
     const long long p = i / CG; const int c0 = 4 * Q * (int)(i - p * CG);
     f32x4 gq[Q], xq[Q], yq[Q], oq[Q];
     ldq(dy + p * lddy + c0, gq);
@@ -335,12 +335,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
-int elem_grid(long long total) {
-  long long g = (total + 255) / 256;
-  if (g > 256 * 16) g = 256 * 16;
-  if (g < 1) g = 1;
-  return (int)g;
-}
+int elem_grid(long long total) { return ssg_elem_grid(total, 4); }     // 4 items per thread: bn_bwd_apply has a per-block prologue (5 fp64 constants per channel)
 
 template <int MODE, typename T>
 int run_reduce(const T* x, const T* y, const T* dy, long long P, int C, int ldx, int ldy, int lddy,

@@ -97,3 +97,21 @@ __device__ __forceinline__ float ssg_swish_grad(float z) {
   const float s = ssg_sigmoid_fast(z);
   return s * (1.f + z * (1.f - s));                                     // utils.py:45-48
 }
+
+// Element-wise kernels: every block owns a CONTIGUOUS chunk of the index range and its threads stride 256 inside it, on a grid of
+// ~total / (256 * items) blocks.  The grid-stride loop over 4096 blocks that these kernels used through round 3 strides 16 MB per
+// iteration (a 1-GiB copy: 4.5-4.8 TB/s); contiguous chunks read 5.4-5.9, one item per thread 6.3 (tools/mfma_lab.hip, `copy`).
+__device__ __forceinline__ long long ssg_chunk_len(long long total) { return (((total + gridDim.x - 1) / gridDim.x) + 255) / 256 * 256; }
+__device__ __forceinline__ long long ssg_chunk_begin(long long total) { return (long long)blockIdx.x * ssg_chunk_len(total); }
+__device__ __forceinline__ long long ssg_chunk_end(long long total) {
+  const long long e = ((long long)blockIdx.x + 1) * ssg_chunk_len(total);
+  return e < total ? e : total;
+}
+#define SSG_CHUNK_LOOP(i, total) \
+  for (long long i = ssg_chunk_begin(total) + threadIdx.x, ssg_end__ = ssg_chunk_end(total); i < ssg_end__; i += 256)
+static inline int ssg_elem_grid(long long total, int items) {
+  long long g = (total + 256ll * items - 1) / (256ll * items);
+  if (g > 0x7fffffffll) g = 0x7fffffffll;
+  if (g < 1) g = 1;
+  return (int)g;
+}

@@ -7,14 +7,8 @@
 
 namespace {
 
-int elem_grid(long long total) {
-  long long g = (total + 255) / 256;
-  if (g > 256 * 32) g = 256 * 32;
-  if (g < 1) g = 1;
-  return (int)g;
-}
-#define GRID_STRIDE(i, total) \
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (total); i += (long long)gridDim.x * 256)
+int elem_grid(long long total) { return ssg_elem_grid(total, 2); }
+#define GRID_STRIDE(i, total) SSG_CHUNK_LOOP(i, total)      // contiguous chunk per block (common.h)
 
 template <typename T>
 struct DwArgs {

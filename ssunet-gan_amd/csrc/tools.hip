@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void mfma_peak_bf16_data_kernel(float* out, in
 // ... and on the v_mfma_f32_16x16x32_bf16 shape (the round-4 k32 kernels): the same output tile per wave (16 accumulators of 4), the
 // same FLOPs per iteration.  On random operands this shape sustains ~1.15x the FLOP/s of 32x32x16 at the clock the chip then holds.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void mfma_peak_bf16_data16_kernel(float* out, int iters, const bf16x8_t* __restrict__ data) {
+__global__ __launch_bounds__(512) void mfma_peak_bf16_data16_kernel(float* out, int iters, const bf16x8_t* __restrict__ data) {
   f32x4_t acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};

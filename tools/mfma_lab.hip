@@ -272,6 +272,21 @@ __global__ __launch_bounds__(256) void copy_four(const f32x4* __restrict__ s, f3
   for (int k = 0; k < 4; ++k) if (i + k * st < nq) d[i + k * st] = v[k];
 }
 
+// each block owns a CONTIGUOUS chunk (blocked partition), threads stride 256 inside it; U loads in flight per thread
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void copy_chunk(const f32x4* __restrict__ s, f32x4* __restrict__ d, long long nq) {
+  const long long per = (nq + gridDim.x - 1) / gridDim.x;
+  const long long b0 = (long long)blockIdx.x * per;
+  long long b1 = b0 + per; if (b1 > nq) b1 = nq;
+  for (long long i = b0 + threadIdx.x; i < b1; i += 256 * U) {
+    f32x4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) if (i + 256 * k < b1) v[k] = NT ? __builtin_nontemporal_load(s + i + 256 * k) : s[i + 256 * k];
+#pragma unroll
+    for (int k = 0; k < U; ++k) if (i + 256 * k < b1) { if (NT) __builtin_nontemporal_store(v[k], d + i + 256 * k); else d[i + 256 * k] = v[k]; }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 template <class F>
 static double time_ms(F&& launch, double seconds) {
@@ -352,8 +367,23 @@ int main(int argc, char** argv) {
     }
   }
 
+  // bench.py's probe geometry: 768 workgroups of 256 threads (3 waves per SIMD), long launches
+  for (int shape : {32, 16}) {
+    const int iters = 200000, wgs = 768;
+    const double ms = time_ms([&] {
+      if (shape == 32) hipLaunchKernelGGL(bare_kernel<32>, dim3(wgs), dim3(256), 0, 0, dout, iters, (const bf16x8*)dbf);
+      else hipLaunchKernelGGL(bare_kernel<16>, dim3(wgs), dim3(256), 0, 0, dout, iters, (const bf16x8*)dbf);
+    }, 0.1);
+    printf("bare %s, random operands, 768 x 256 threads x %d iterations: %8.3f ms  %7.1f TFLOP/s\n", shape == 32 ? "32x32x16" : "16x16x32", iters, ms,
+           (double)wgs * 4 * iters * 16 * 32768.0 / ms / 1e9);
+    fflush(stdout);
+  }
+  if (argc > 2 && !strcmp(argv[2], "bare")) return 0;
+
   // ---- ring skeletons
+  const bool only_copy = argc > 2 && !strcmp(argv[2], "copy");
   RingArgs a{dw, dpx, PXF, dbf, dout, 0, NSRC};
+  if (!only_copy) {
   a.nsteps = 36 * 8;                                      // 8 tiles' worth of a Cin = 128 layer per workgroup
   //                 SHAPE NW  BM   BN  WM WN refresh barrier dma
   run_ring<32, 4, 128,  64, 4, 1, false, true, true>("A  256thr 128x64 32x32x16 4x1", a, 512, secs);
@@ -368,16 +398,26 @@ int main(int argc, char** argv) {
   run_ring<16, 8, 256, 128, 4, 2, false, false, false>("Cnn  ... neither (LDS reads + MFMA only)", a, 256, secs);
   run_ring<16, 4, 128,  64, 4, 1, true,  true, true>("Br 256thr 128x64 16x16x32 4x1 +refresh", a, 512, secs);
 
+  }
   // ---- copies (1 GiB -> reuse dpx as source, second buffer as destination)
   float* dd; CK(hipMalloc(&dd, PXF * 4));
   const long long nq = PXF / 4;
-  struct { const char* n; int kind; } cps[] = {{"copy grid-stride 4096 WGs", 0}, {"copy one float4 per thread", 1}, {"copy one float4 per thread, nt", 2}, {"copy 4 float4 per thread", 3}};
+  struct { const char* n; int kind; } cps[] = {{"copy grid-stride 4096 WGs", 0}, {"copy one float4 per thread", 1}, {"copy one float4 per thread, nt", 2}, {"copy 4 float4 per thread", 3},
+                                               {"copy contiguous chunks, 4096 WGs, 1 in flight", 4}, {"copy contiguous chunks, 4096 WGs, 2 in flight", 5},
+                                               {"copy contiguous chunks, 4096 WGs, 4 in flight", 6}, {"copy contiguous chunks, 4096 WGs, 4 in flight, nt", 7},
+                                               {"copy contiguous chunks, 16384 WGs, 2 in flight", 8}, {"copy contiguous chunks, 65536 WGs, 1 in flight", 9}};
   for (auto& c : cps) {
     const double ms = time_ms([&] {
       if (c.kind == 0) hipLaunchKernelGGL(copy_gs, dim3(4096), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
       else if (c.kind == 1) hipLaunchKernelGGL(copy_one, dim3((unsigned)(nq / 256)), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
       else if (c.kind == 2) hipLaunchKernelGGL(copy_one_nt, dim3((unsigned)(nq / 256)), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
-      else hipLaunchKernelGGL(copy_four, dim3((unsigned)(nq / 1024)), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
+      else if (c.kind == 3) hipLaunchKernelGGL(copy_four, dim3((unsigned)(nq / 1024)), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
+      else if (c.kind == 4) hipLaunchKernelGGL((copy_chunk<1, false>), dim3(4096), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
+      else if (c.kind == 5) hipLaunchKernelGGL((copy_chunk<2, false>), dim3(4096), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
+      else if (c.kind == 6) hipLaunchKernelGGL((copy_chunk<4, false>), dim3(4096), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
+      else if (c.kind == 7) hipLaunchKernelGGL((copy_chunk<4, true>), dim3(4096), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
+      else if (c.kind == 8) hipLaunchKernelGGL((copy_chunk<2, false>), dim3(16384), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
+      else hipLaunchKernelGGL((copy_chunk<1, false>), dim3(65536), dim3(256), 0, 0, (const f32x4*)dpx, (f32x4*)dd, nq);
     }, 0.5);
     printf("%-36s %8.3f ms  %6.2f TB/s (read + write)\n", c.n, ms, 2.0 * PXF * 4 / ms / 1e9);
     fflush(stdout);
