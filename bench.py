@@ -139,6 +139,71 @@ def measured_ceilings(S, dev):
             'hbm_copy_form': 'one float4 per thread, non-temporal, 1 GiB -> 1 GiB (the grid-stride probe of rounds 1-3 read 4.6-4.8)'}
 
 
+def _under_profiler():
+    preload = ' '.join(os.environ.get(k, '') for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB'))
+    return 'rocprof' in preload.lower() or any(k.startswith('ROCPROFILER_') or k.startswith('ROCPROF_') for k in os.environ)
+
+
+def side_configs(S, dev, note):
+    """Short legs for the other BASELINE configs, so that the driver's own run carries them; ~20 s in all.
+    config 4: EfficientNet-B4 extract_features fwd+bwd, 4 x 3x1024x1024, bf16 -- eager and as a hipGraph replay (tools/bench_b4.py is
+    the long form with the per-kernel table).  config 5: eval-mode generator over the 36 patches of a 2048^2 image, batch 12 and the
+    reference's batch 1 (tools/bench_extra.py).  dp_costs: a CHILD run of this script with SSG_DIST_FORCE=1 (world 1, every
+    collective of the data-parallel path through RCCL) -- what the sync-BN and gradient-bucket all-reduces cost on this box."""
+    import types
+    out = {}
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import bench_b4
+        a4 = types.SimpleNamespace(batch=4, size=1024, steps=4, warmup=2)
+        dte, _ = bench_b4.run(torch.bfloat16, a4, dev, False)
+        try:
+            dtg, ok = bench_b4.run_graph(torch.bfloat16, a4, dev)
+            graph = {'images_per_s': round(4 / dtg, 2), 'ms_per_step': round(dtg * 1e3, 2), 'finite_grads': bool(ok)}
+        except Exception as e:
+            graph = {'error': type(e).__name__}
+        out['config4_b4_bf16'] = {'workload': 'EfficientNet-B4 extract_features fwd+bwd, 4 x 3x1024x1024, bf16 tensors, train mode', 'steps': 4,
+                                  'eager': {'images_per_s': round(4 / dte, 2), 'ms_per_step': round(dte * 1e3, 2)}, 'hipgraph_replay': graph}
+        note('config 4: bf16 B4 %.1f img/s eager' % (4 / dte))
+    except Exception as e:                       # a side leg must never cost the headline line
+        out['config4_b4_bf16'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    try:
+        torch.manual_seed(41)
+        G = S.models_seg_gan.Generator(dict(arch='UNet_R_SS_v2', num_classes=3, input_channels=3, deep_supervision=False)).to(dev)
+        patches = torch.randn(36, 3, 512, 512, generator=torch.Generator().manual_seed(7))
+        c5 = {'workload': 'eval-mode G (BN folded) over the 36 patches (3x512x512) of a 2048^2 image, incl. H2D / D2H'}
+        for bs in (12, 1):
+            S.aerial_image_segmentation_api.infer_patches(G, patches, batch_size=bs)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(2):
+                S.aerial_image_segmentation_api.infer_patches(G, patches, batch_size=bs)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 2
+            c5['batch_%d' % bs] = {'patches_per_s': round(36 / dt, 1), 's_per_image': round(dt, 3)}
+        out['config5_infer'] = c5
+        del G
+        torch.cuda.empty_cache()
+        note('config 5: %.0f patches/s batched by 12' % c5['batch_12']['patches_per_s'])
+    except Exception as e:
+        out['config5_infer'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if os.environ.get('SSG_DIST_FORCE') != '1' and not _under_profiler():
+        try:
+            env = dict(os.environ, SSG_DIST_FORCE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-fp32-reference',
+                                '--no-side-configs'], env=env, capture_output=True, text=True, timeout=240)
+            line = next((json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')), None)
+            if line is None:
+                out['dp_costs'] = {'error': 'child exited %d: %s' % (r.returncode, r.stderr[-300:])}
+            else:
+                out['dp_costs'] = {'how': 'child run with SSG_DIST_FORCE=1: world 1, sync-BN statistics, gradient buckets and metric sums through RCCL',
+                                   'backend': line.get('backend'), 'ms_per_step': line.get('ms_per_step'),
+                                   'sync_bn_allreduce': line.get('sync_bn_allreduce'), 'sync_bn_allreduce_ms': line.get('sync_bn_allreduce_ms'),
+                                   'grad_bucket_allreduce': line.get('grad_bucket_allreduce')}
+                note('dp costs (world 1 over RCCL): sync-BN all-reduces %.2f ms/step' % (line.get('sync_bn_allreduce_ms') or float('nan')))
+        except Exception as e:
+            out['dp_costs'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return out
+
+
 def host_cores():
     """Threads this process may really use: the cgroup CPU quota if there is one (a GPU box gives a
     1-GPU job a share of its host, although affinity still lists every core), else the affinity
@@ -160,6 +225,18 @@ def host_cores():
     return max(1, min(n, 16))          # the pool's per-GPU CPU share is 16 cores
 
 
+def cpu_model():
+    """CPU model string of the host (BASELINE.md 3 asks for it beside the core count)."""
+    try:
+        for l in open('/proc/cpuinfo'):
+            if l.lower().startswith('model name'):
+                return l.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(seconds_budget=30.0):
     """Oracle (plain torch CPU restatement, pinned to the reference's golden vectors) timed on a
     bounded sample: 1 x 3 x 512 x 512 steps (the GPU workload is 16 such images per step)."""
@@ -173,15 +250,16 @@ def cpu_baseline(seconds_budget=30.0):
     O.gan_step(G, D, og, od, inp, tgt)                      # warm-up (also sizes the sample)
     warm = time.time() - t0
     print('[bench] cpu baseline warm-up step: %.1f s' % warm, file=sys.stderr, flush=True)
+    cpu = cpu_model()
     if warm > seconds_budget / 2:                           # slow host: the warm-up step IS the sample
-        return {'value': round(1.0 / warm, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+        return {'value': round(1.0 / warm, 4), 'unit': 'images/sec', 'cores': cores, 'cpu_model': cpu, 'kind': 'port',
                 'sample': '1 G+D step (first call, no warm-up) on 1x3x512x512, fp32, torch %d threads' % cores}
     n = max(1, min(3, int((seconds_budget - warm) / max(warm, 1e-3))))
     t0 = time.time()
     for _ in range(n):
         O.gan_step(G, D, og, od, inp, tgt)
     dt = (time.time() - t0) / n
-    return {'value': round(1.0 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+    return {'value': round(1.0 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'cpu_model': cpu, 'kind': 'port',
             'sample': '%d timed G+D steps (after 1 warm-up) on 1x3x512x512, fp32, torch %d threads' % (n, cores)}
 
 
@@ -259,6 +337,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-reference', action='store_true', help='skip the extra steps with every conv on the fp32 MFMA')
     ap.add_argument('--launch-check', action='store_true', help='rendezvous only, no GPU step (CPU rehearsal of the N-rank launch)')
+    ap.add_argument('--no-side-configs', action='store_true', help='skip the short legs for BASELINE configs 4 / 5 and the world-1 RCCL cost run')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -481,6 +560,8 @@ def main():
             if roof and roof.get('executed') and line['measured_ceilings'].get('mfma_bf16_random_operand_tflops'):
                 key = 'mfma_bf16_16x16x32_random_operand_tflops' if 'k32' in roof['kernel'] else 'mfma_bf16_random_operand_tflops'
                 roof['executed']['frac_of_measured_random_operand_rate'] = round(roof['executed']['achieved'] / line['measured_ceilings'][key], 4)
+        if world == 1 and not args.no_side_configs and os.environ.get('SSG_DIST_FORCE') != '1':
+            line.update(side_configs(S, dev, note))
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -52,6 +52,24 @@ def _step_optimizer(optimizer, grad_clip):
 ELIDE_DEAD_D_GRADS = os.environ.get('SSG_ELIDE_DEAD_D_GRADS', '0') == '1'
 
 
+class _stage(object):
+    """Profiler range around one stage of the step: torch.cuda.nvtx is roctx on ROCm, so
+    `rocprofv3 --marker-trace --kernel-trace` splits a step into G forward / losses / G backward / G optimizer / D forwards /
+    D backward / D optimizer.  SSG_MARKERS=0 switches the ranges off (they cost ~1 us each)."""
+    ON = os.environ.get('SSG_MARKERS', '1') != '0'
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _stage.ON:
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *a):
+        if _stage.ON:
+            torch.cuda.nvtx.range_pop()
+
+
 class _params_frozen(object):
     """Run a forward with the module's parameters not requiring grad (restored on exit)."""
 
@@ -70,10 +88,12 @@ class _params_frozen(object):
 def gan_step(input, target, generator, discriminator, criterion, adversarial_loss_criterion, content_loss_criterion,
              optimizer_g, optimizer_d, num_class, sync_g=None, sync_d=None):
     """One iteration of train_seg_gan.py:182-233.  Returns device scalars (loss, iou, dice, closs, adv_g, adv_d)."""
-    generator_output = generator(input)                                        # :188
-    generator_output = ops.nan_to_zero_(generator_output)                      # :190
+    with _stage('ssg.G_forward'):
+        generator_output = generator(input)                                    # :188
+        generator_output = ops.nan_to_zero_(generator_output)                  # :190
     fused = isinstance(criterion, BCEDiceLoss) and isinstance(content_loss_criterion, nn.MSELoss) \
         and content_loss_criterion.reduction == 'mean'
+    torch.cuda.nvtx.range_push('ssg.losses_and_D_forward_1') if _stage.ON else None
     if fused:
         res, msums = ops.seg_loss(generator_output, target, metric_first_channel=1, with_sums=True)   # :191-198 in one pass
         loss, content_loss, iou, dice = res[0], res[1], res[4], res[5]
@@ -94,27 +114,33 @@ def gan_step(input, target, generator, discriminator, criterion, adversarial_los
     adversarial_loss = _adv_loss(adversarial_loss_criterion, seg_discriminated, 1.0)
     perceptual_loss = loss + ALPA * content_loss + BETA * adversarial_loss     # :205
     adv_g = adversarial_loss.detach()
+    torch.cuda.nvtx.range_pop() if _stage.ON else None
 
     optimizer_g.zero_grad()
-    if sync_g is not None:
-        sync_g.begin()
-    perceptual_loss.backward()
-    if sync_g is not None:
-        sync_g.finish()
-    _step_optimizer(optimizer_g, GRAD_CLIP)                                    # :211-215
+    with _stage('ssg.G_step_backward'):
+        if sync_g is not None:
+            sync_g.begin()
+        perceptual_loss.backward()
+        if sync_g is not None:
+            sync_g.finish()
+    with _stage('ssg.G_optimizer'):
+        _step_optimizer(optimizer_g, GRAD_CLIP)                                # :211-215
 
-    hr_discriminated = discriminator(target)                                   # :217
-    sr_discriminated = discriminator(generator_output.detach())                # :218
-    adversarial_loss = _adv_loss(adversarial_loss_criterion, sr_discriminated, 0.0) + \
-        _adv_loss(adversarial_loss_criterion, hr_discriminated, 1.0)
+    with _stage('ssg.D_forward_2_3'):
+        hr_discriminated = discriminator(target)                               # :217
+        sr_discriminated = discriminator(generator_output.detach())            # :218
+        adversarial_loss = _adv_loss(adversarial_loss_criterion, sr_discriminated, 0.0) + \
+            _adv_loss(adversarial_loss_criterion, hr_discriminated, 1.0)
 
     optimizer_d.zero_grad()                                                    # :225 drops D grads of the G step
-    if sync_d is not None:
-        sync_d.begin()
-    adversarial_loss.backward()
-    if sync_d is not None:
-        sync_d.finish()
-    _step_optimizer(optimizer_d, GRAD_CLIP)                                    # :229-233
+    with _stage('ssg.D_step_backward'):
+        if sync_d is not None:
+            sync_d.begin()
+        adversarial_loss.backward()
+        if sync_d is not None:
+            sync_d.finish()
+    with _stage('ssg.D_optimizer'):
+        _step_optimizer(optimizer_d, GRAD_CLIP)                                # :229-233
     return dp.reduce_mean(loss), iou.detach(), dice.detach(), content_loss.detach(), adv_g, adversarial_loss.detach()
 
 
