@@ -32,9 +32,11 @@ namespace {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef SSG_K32_PROBE
-// diagnostic build only (tools/k32_probe.py): per workgroup s_memtime at kernel start / loop start / loop end / kernel end
+// diagnostic build only (tools/k32_probe.py): per workgroup s_memtime at kernel start / loop start / loop end / kernel end (+ s_memrealtime,
+// 100 MHz, at the first and last: the in-kernel clock)
 __device__ unsigned long long* ssg_probe_buf_k32 = nullptr;
-#define SSG_STAMP(i) do { if (ssg_probe_buf_k32 && tid == 0) ssg_probe_buf_k32[4 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SSG_STAMP(i) do { if (ssg_probe_buf_k32 && tid == 0) { ssg_probe_buf_k32[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); \
+                                                            if ((i) == 0 || (i) == 3) ssg_probe_buf_k32[8 * blockIdx.x + 4 + ((i) == 3)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define SSG_STAMP(i) do { } while (0)
 #endif
@@ -206,6 +208,21 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       const int toff = (((tb & 7) - 2) * HW + ((tb >> 3) - 2)) * 16;
       const unsigned char* st = ring + (t % 3) * BSTG + wfrag;            // s % 3 == t % 3 (9 steps per chunk)
       bf16x8 p[MI][3], w[NI][3];
+#ifndef SSG_K32_READ_ORDER
+#define SSG_K32_READ_ORDER 0                               // 1: fragments are read in the order the six product terms consume them (A/B build switch: +-0 on <8,128>, 31 spills on <16,64>)
+#endif
+#if SSG_K32_READ_ORDER
+      // LDS returns reads in order and all eight waves read at once behind the barrier: the planes of the first term (w3, p1) first, so
+      // that its MFMAs start after a third of the burst instead of all of it
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int qp = r, qw = 2 - r;                    // term order: (w3, p1), (w2, p2), (w1, p3), ...
+#pragma unroll
+        for (int i = 0; i < MI; ++i) p[i][qp] = *(const bf16x8*)(img + qp * PLANE + pb[i] + toff);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) w[j][qw] = *(const bf16x8*)(st + (j * 3 + qw) * 1024);
+      }
+#else
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -214,6 +231,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int q = 0; q < 3; ++q) w[j][q] = *(const bf16x8*)(st + (j * 3 + q) * 1024);
+#endif
       // small terms first
 #define SSG_K32_TERM(QW, QP)                                                                      \
   _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                  \

@@ -174,7 +174,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
       asm volatile("" ::: "memory");
       const bool more = gy + 1 < gb;
       Raw nx, nd;
+#ifndef SSG_WK32_LOAD_MID
+#define SSG_WK32_LOAD_MID 0                                // 1: the next rows' loads go out after the first tap row's MFMAs instead of behind the barrier (A/B build switch)
+#endif
+#if !SSG_WK32_LOAD_MID
       if (more) { nx = load_x(n, gy + 2, gx0); nd = load_d(n, gy + 1, gx0); }
+#endif
 
       const unsigned char* db = dimg + (gy & 1) * DSLOT;
       bf16x8 df[2][3];
@@ -199,6 +204,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
         SSG_WK_TERM(1, 0) SSG_WK_TERM(0, 1)
         SSG_WK_TERM(0, 0)
 #undef SSG_WK_TERM
+#if SSG_WK32_LOAD_MID
+        if (dyi == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) { nx = load_x(n, gy + 2, gx0); nd = load_d(n, gy + 1, gx0); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
       }
       if (more) {
         __builtin_amdgcn_sched_barrier(0);
