@@ -102,6 +102,12 @@ __device__ __forceinline__ float ssg_swish_grad(float z) {
 // ~total / (256 * items) blocks.  The grid-stride loop over 4096 blocks that these kernels used through round 3 strides 16 MB per
 // iteration (a 1-GiB copy: 4.5-4.8 TB/s); contiguous chunks read 5.4-5.9, one item per thread 6.3 (tools/mfma_lab.hip, `copy`).
 __device__ __forceinline__ long long ssg_chunk_len(long long total) { return (((total + gridDim.x - 1) / gridDim.x) + 255) / 256 * 256; }
+// Workgroup ids are dealt to the 8 XCDs round-robin; map id -> position so that XCD k owns the k-th contiguous band of [0, n) and
+// walks it in dispatch order (neighbouring positions then share one L2).
+__device__ __forceinline__ unsigned ssg_xcd_band(unsigned id, unsigned n) {
+  const unsigned per = n >> 3, rem = n & 7u, k = id & 7u;
+  return k * per + (k < rem ? k : rem) + (id >> 3);
+}
 __device__ __forceinline__ long long ssg_chunk_begin(long long total) { return (long long)blockIdx.x * ssg_chunk_len(total); }
 __device__ __forceinline__ long long ssg_chunk_end(long long total) {
   const long long e = ((long long)blockIdx.x + 1) * ssg_chunk_len(total);

@@ -88,6 +88,9 @@ __global__ __launch_bounds__(256) void gather2x2_kernel(const float* __restrict_
 // ATen: scale = (in-1)/(out-1) (0 if out==1); src = scale*dst; i0 = (int)src; i1 = i0 + (i0 < in-1);
 //       l1 = src - i0; l0 = 1 - l1.
 __device__ __forceinline__ void lerp_coord(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+  // the product is ROUNDED before the subtraction below (ATen's kernels do): left to the compiler it is contracted into
+  // fma(scale, o, -i0), which moves the weight by up to half an ulp of the coordinate (1.4e-5 of the result at 2H = 140)
+#pragma clang fp contract(off)
   const float s = scale * (float)o;
   i0 = (int)s;
   if (i0 > in - 1) i0 = in - 1;
@@ -96,13 +99,19 @@ __device__ __forceinline__ void lerp_coord(int o, float scale, int in, int& i0, 
   l0 = 1.f - l1;
 }
 
-// One workgroup row of the grid = one output image row (blockIdx.x = n * OH + oy): the row's vertical coordinates are computed
+// Linear workgroup ids go round-robin over the 8 XCDs, each with its own L2; an output row and its neighbours read the same two
+// source rows, so dealing consecutive rows to different XCDs made every L2 fetch the source on its own (r3/r4_a PMC: 6.6x the
+// source bytes from HBM in the forward, 2.3x the gradient bytes in the backward).  ssg_xcd_band gives each XCD one contiguous band
+// of rows instead, walked in order.
+// One workgroup = one part of one output image row (n * OH + oy): the row's vertical coordinates are computed
 // once and the column index stays 32-bit (the flat 64-bit index of round 1 spent three 64-bit divisions per 16 bytes written:
 // 2.9 TB/s on a write-bound pass).
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
-                                                           float* __restrict__ y, int ldy, float sy, float sx) {
+                                                           float* __restrict__ y, int ldy, float sy, float sx, unsigned parts) {
   const int OH = 2 * H, OW = 2 * W, CQ = C / 4;
-  const int row = blockIdx.x;
+  const unsigned v = ssg_xcd_band(blockIdx.x, gridDim.x);
+  const int row = (int)(v / parts);
+  const unsigned part = v - (unsigned)row * parts;
   const int n = row / OH, oy = row - n * OH;
   int y0, y1; float ly0, ly1;
   lerp_coord(oy, sy, H, y0, y1, ly0, ly1);
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
   const float* b1 = x + ((size_t)n * H + y1) * W * ldx;
   float* out = y + (size_t)row * OW * ldy;
   const unsigned cols = (unsigned)OW * (unsigned)CQ;
-  for (unsigned j = blockIdx.y * 256u + threadIdx.x; j < cols; j += gridDim.y * 256u) {
+  for (unsigned j = part * 256u + threadIdx.x; j < cols; j += parts * 256u) {
     const unsigned ox = j / (unsigned)CQ, cq = j - ox * (unsigned)CQ;
     int x0, x1; float lx0, lx1;
     lerp_coord((int)ox, sx, W, x0, x1, lx0, lx1);
@@ -132,14 +141,16 @@ __device__ __forceinline__ void cand_range(int i, float scale, int out, int& lo,
 }
 
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int lddy, int N, int H, int W, int C,
-                                                           float* __restrict__ dx, int lddx, float sy, float sx) {
+                                                           float* __restrict__ dx, int lddx, float sy, float sx, unsigned parts) {
   const int OH = 2 * H, OW = 2 * W, CQ = C / 4;
-  const int row = blockIdx.x;                             // n * H + iy
+  const unsigned v = ssg_xcd_band(blockIdx.x, gridDim.x);
+  const int row = (int)(v / parts);                       // n * H + iy
+  const unsigned part = v - (unsigned)row * parts;
   const int n = row / H, iy = row - n * H;
   int ylo, yhi;
   cand_range(iy, sy, OH, ylo, yhi);
   const unsigned cols = (unsigned)W * (unsigned)CQ;
-  for (unsigned j = blockIdx.y * 256u + threadIdx.x; j < cols; j += gridDim.y * 256u) {
+  for (unsigned j = part * 256u + threadIdx.x; j < cols; j += parts * 256u) {
     const int ix = (int)(j / (unsigned)CQ), cq = (int)(j - (unsigned)ix * (unsigned)CQ);
     int xlo, xhi;
     cand_range(ix, sx, OW, xlo, xhi);
@@ -167,6 +178,110 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     }
     *(f32x4*)(dx + ((size_t)(n * H + iy) * W + ix) * lddx + 4 * cq) = acc;
   }
+}
+
+// ---------------------------------------------------------------- bilinear x2, streaming forms (C % 16 == 0)
+// The gather kernels above issue four 16-byte loads per 16 bytes written (forward) and scan a 7 x 7 candidate window per input
+// pixel (backward): 3.1-3.5 TB/s of algorithmic bytes at the decoder's shapes even with the XCD bands (tools/micro_spatial.py).
+// Here a thread owns one (column, channel quad) and walks DOWN a band of rows with the horizontal work kept in registers:
+//   forward : h(y) = lx0 * x[y][x0] + lx1 * x[y][x1] of the two live source rows; out[oy] = ly0 * h(y0) + ly1 * h(y1); a new
+//             source row costs two loads, an output row one store (one load per output element instead of four);
+//   backward: h(oy) = sum over the <= 5 output columns that read input column ix of their weight * dy[oy][ox]; the two live input
+//             rows accumulate ly0 * h and ly1 * h and leave in row order (the vertical index never moves by more than one per
+//             output row: scale < 1) -- every gradient element is loaded by the <= 2 threads whose columns it feeds.
+// Same arithmetic grouping as the gather kernels (ly * (lx * v)), rows in ascending order: the results agree to the last bit
+// except where x0 == x1 (last column), whose two weights are added before the multiply.
+constexpr int BIL_FWD_BAND = 32;                         // output rows per workgroup
+constexpr int BIL_BWD_BAND = 16;                         // input rows per workgroup
+
+template <int CQT>                                       // channel quads per workgroup (16 / 8 / 4); 256 / CQT columns
+__global__ __launch_bounds__(256) void bilinear_fwd_stream_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
+                                                                  float* __restrict__ y, int ldy, float sy, float sx,
+                                                                  int nct, int ncb, int nbands) {
+  constexpr int OXT = 256 / CQT;
+  const int OH = 2 * H, OW = 2 * W;
+  unsigned u = blockIdx.x;
+  const int ct = (int)(u % (unsigned)nct); u /= (unsigned)nct;
+  const int cb = (int)(u % (unsigned)ncb); u /= (unsigned)ncb;
+  const int band = (int)(u % (unsigned)nbands);
+  const int n = (int)(u / (unsigned)nbands);
+  const int cq = threadIdx.x % CQT, oxl = threadIdx.x / CQT;
+  const int ox = cb * OXT + oxl;
+  if (ox >= OW) return;
+  const int c4 = (ct * CQT + cq) * 4;
+  int x0, x1; float lx0, lx1;
+  lerp_coord(ox, sx, W, x0, x1, lx0, lx1);
+  const float* p0 = x + ((size_t)n * H * W + x0) * ldx + c4;
+  const float* p1 = x + ((size_t)n * H * W + x1) * ldx + c4;
+  const size_t rs = (size_t)W * ldx;
+  float* out = y + ((size_t)n * OH * OW + ox) * ldy + c4;
+  const int o0 = band * BIL_FWD_BAND, o1 = min(o0 + BIL_FWD_BAND, OH);
+  auto hrow = [&](int r) { return lx0 * *(const f32x4*)(p0 + (size_t)r * rs) + lx1 * *(const f32x4*)(p1 + (size_t)r * rs); };
+  int y0, y1; float ly0, ly1;
+  lerp_coord(o0, sy, H, y0, y1, ly0, ly1);
+  int cur = y0;
+  f32x4 h0 = hrow(cur), h1 = hrow(min(cur + 1, H - 1));
+  for (int oy = o0; oy < o1; ++oy) {
+    lerp_coord(oy, sy, H, y0, y1, ly0, ly1);
+    if (y0 > cur) { cur = y0; h0 = h1; h1 = hrow(min(cur + 1, H - 1)); }      // y0 == cur + 1: the scale is below one
+    *(f32x4*)(out + (size_t)oy * OW * ldy) = ly0 * h0 + ly1 * h1;               // y1 == y0 only on the last row, where h1 == h0
+  }
+}
+
+template <int CQT>
+__global__ __launch_bounds__(256) void bilinear_bwd_stream_kernel(const float* __restrict__ dy, int lddy, int N, int H, int W, int C,
+                                                                  float* __restrict__ dx, int lddx, float sy, float sx,
+                                                                  int nct, int ncb, int nbands) {
+  constexpr int IXT = 256 / CQT;
+  const int OH = 2 * H, OW = 2 * W;
+  unsigned u = blockIdx.x;
+  const int ct = (int)(u % (unsigned)nct); u /= (unsigned)nct;
+  const int cb = (int)(u % (unsigned)ncb); u /= (unsigned)ncb;
+  const int band = (int)(u % (unsigned)nbands);
+  const int n = (int)(u / (unsigned)nbands);
+  const int cq = threadIdx.x % CQT, ixl = threadIdx.x / CQT;
+  const int ix = cb * IXT + ixl;
+  if (ix >= W) return;
+  const int c4 = (ct * CQT + cq) * 4;
+  // the output columns that read input column ix: a run of <= 5 (ox * sx in [ix - 1, ix + 1), sx >= 0.4: the launcher's condition)
+  int xlo, xhi;
+  cand_range(ix, sx, OW, xlo, xhi);
+  int oxf = -1, cnt = 0; float wx[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int ox = xlo; ox <= xhi; ++ox) {
+    int x0, x1; float lx0, lx1;
+    lerp_coord(ox, sx, W, x0, x1, lx0, lx1);
+    if (x0 != ix && x1 != ix) continue;
+    if (oxf < 0) oxf = ox;
+    const float wgt = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+    const int k = ox - oxf;
+    if (k < 5) cnt = k + 1;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) if (q == k) wx[q] = wgt;
+  }
+  const int b0 = band * BIL_BWD_BAND, b1 = min(b0 + BIL_BWD_BAND, H);
+  int oylo, oyhi, t;
+  cand_range(b0, sy, OH, oylo, t);
+  cand_range(b1 - 1, sy, OH, t, oyhi);
+  const float* src = dy + ((size_t)n * OH * OW + (oxf < 0 ? 0 : oxf)) * lddy + c4;
+  float* dst = dx + ((size_t)n * H * W + ix) * lddx + c4;
+  auto flush = [&](int r, const f32x4& v) { if (r >= b0 && r < b1) *(f32x4*)(dst + (size_t)r * W * lddx) = v; };
+  int y0, y1; float ly0, ly1;
+  lerp_coord(oylo, sy, H, y0, y1, ly0, ly1);
+  int cur = y0;
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  for (int oy = oylo; oy <= oyhi; ++oy) {
+    lerp_coord(oy, sy, H, y0, y1, ly0, ly1);
+    const float* row = src + (size_t)oy * OW * lddy;
+    f32x4 h = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (q < cnt) h += wx[q] * *(const f32x4*)(row + (size_t)q * lddy);
+    if (y0 > cur) { flush(cur, acc0); acc0 = acc1; acc1 = f32x4{0, 0, 0, 0}; cur = y0; }
+    acc0 += ly0 * h;
+    if (y1 != y0) acc1 += ly1 * h; else acc0 += ly1 * h;
+  }
+  flush(cur, acc0);
+  flush(cur + 1, acc1);
 }
 
 // ---------------------------------------------------------------- nearest x2
@@ -254,6 +369,11 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
   for (int c = threadIdx.x >> 6; c < C; c += 4) dst[((size_t)n * C + c) * S + p] = src[((size_t)n * S + p) * ld + c];
 }
 
+// streaming bilinear kernels: 16-channel tiles, scales in [0.4, 0.5) on both axes (H, W >= 3), a grid that fits 32 bits
+static bool bilinear_stream_ok(int N, int H, int W, int C) {
+  static const int on = [] { const char* e = getenv("SSG_BILINEAR_STREAM"); return e ? atoi(e) : 1; }();
+  return on && C % 16 == 0 && H >= 3 && W >= 3 && (long long)N * (2 * H / BIL_FWD_BAND + 1) * (2 * W / 16 + 1) * (C / 16) < (1ll << 31);
+}
 #define REQ_Q(C, ...) SSG_REQUIRE((C) > 0 && (C) % 4 == 0, SSG_EINVAL, __VA_ARGS__)
 
 }  // namespace
@@ -305,9 +425,20 @@ extern "C" int ssg_upsample2x_bilinear_fwd_f32(const float* x, int N, int H, int
   REQ_Q(C, "bilinear: C %% 4");
   const float sy = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f, sx = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
   SSG_REQUIRE((long long)N * 2 * H < (1ll << 31) && (long long)2 * W * (C / 4) < (1ll << 31), SSG_EINVAL, "bilinear: too large");
+  if (bilinear_stream_ok(N, H, W, C)) {
+    const int cqt = C % 64 == 0 ? 16 : C % 32 == 0 ? 8 : 4;
+    const int nct = C / (4 * cqt), ncb = (2 * W + 256 / cqt - 1) / (256 / cqt), nb = (2 * H + BIL_FWD_BAND - 1) / BIL_FWD_BAND;
+    const dim3 grid((unsigned)((long long)N * nb * ncb * nct));
+    if (cqt == 16) hipLaunchKernelGGL(bilinear_fwd_stream_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ldx, y, ldy, sy, sx, nct, ncb, nb);
+    else if (cqt == 8) hipLaunchKernelGGL(bilinear_fwd_stream_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ldx, y, ldy, sy, sx, nct, ncb, nb);
+    else hipLaunchKernelGGL(bilinear_fwd_stream_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ldx, y, ldy, sy, sx, nct, ncb, nb);
+    SSG_LAUNCH_CHECK();
+    return SSG_OK;
+  }
   const unsigned cols = (unsigned)(2 * W) * (unsigned)(C / 4);
   const unsigned gy = cols / 1024 ? (cols / 1024 > 64 ? 64 : cols / 1024) : 1;              // ~4 column steps per thread
-  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3((unsigned)(N * 2 * H), gy), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ldx, y, ldy, sy, sx);
+  SSG_REQUIRE((long long)N * 2 * H * gy < (1ll << 31), SSG_EINVAL, "bilinear: too large");
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3((unsigned)(N * 2 * H) * gy), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ldx, y, ldy, sy, sx, gy);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -316,9 +447,20 @@ extern "C" int ssg_upsample2x_bilinear_bwd_f32(const float* dy, int lddy, int N,
   REQ_Q(C, "bilinear_bwd: C %% 4");
   const float sy = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f, sx = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
   SSG_REQUIRE((long long)N * H < (1ll << 31) && (long long)W * (C / 4) < (1ll << 31), SSG_EINVAL, "bilinear_bwd: too large");
+  if (bilinear_stream_ok(N, H, W, C)) {
+    const int cqt = C % 64 == 0 ? 16 : C % 32 == 0 ? 8 : 4;
+    const int nct = C / (4 * cqt), ncb = (W + 256 / cqt - 1) / (256 / cqt), nb = (H + BIL_BWD_BAND - 1) / BIL_BWD_BAND;
+    const dim3 grid((unsigned)((long long)N * nb * ncb * nct));
+    if (cqt == 16) hipLaunchKernelGGL(bilinear_bwd_stream_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, N, H, W, C, dx, lddx, sy, sx, nct, ncb, nb);
+    else if (cqt == 8) hipLaunchKernelGGL(bilinear_bwd_stream_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, N, H, W, C, dx, lddx, sy, sx, nct, ncb, nb);
+    else hipLaunchKernelGGL(bilinear_bwd_stream_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, N, H, W, C, dx, lddx, sy, sx, nct, ncb, nb);
+    SSG_LAUNCH_CHECK();
+    return SSG_OK;
+  }
   const unsigned cols = (unsigned)W * (unsigned)(C / 4);
   const unsigned gy = (cols + 255) / 256 > 64 ? 64 : (cols + 255) / 256;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)(N * H), gy), dim3(256), 0, (hipStream_t)stream, dy, lddy, N, H, W, C, dx, lddx, sy, sx);
+  SSG_REQUIRE((long long)N * H * gy < (1ll << 31), SSG_EINVAL, "bilinear_bwd: too large");
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)(N * H) * gy), dim3(256), 0, (hipStream_t)stream, dy, lddy, N, H, W, C, dx, lddx, sy, sx, gy);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
