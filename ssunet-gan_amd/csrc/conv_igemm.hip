@@ -298,7 +298,12 @@ ConvArgs to_args(const ssg_conv_desc* d) {
 
 // column tile (64 / 128; 1064 / 1128 = the k32 pack format of conv_igemm_halo_k32.hip) of the split-operand kernel for `d`, or 0: 3x3 unit-stride launches on the halo path that would not split K
 int split_bn(const ssg_conv_desc* d) {
-  if (!uses_dma(d) || d->Cout <= 32) return 0;
+  if (d->Cout <= 32) {                                          // narrow k32 tiles (1016 / 1032), or nothing
+    if (d->kmode != 0 || d->parity_merge) return 0;
+    const ConvArgs a = to_args(d);
+    return uses_halo(a) ? ssg_conv_halo_k32_fmt(a) : 0;
+  }
+  if (!uses_dma(d)) return 0;
   const ConvArgs a = to_args(d);
   if (d->parity_merge) return ssg_conv_halo_x3_parity_ok(a) ? 64 : 0;
   if (!uses_halo(a)) return ssg_conv_dma_x3_bn(a);            // 1x1, stride 2, parity-class launches: the LDS-DMA pipeline
@@ -316,7 +321,9 @@ int split_bn(const ssg_conv_desc* d) {
 // statistics epilogue (thin / register-staged kernels): the caller then runs ssg_bn_stats_f32 instead
 extern "C" int ssg_conv2d_bnpart_rows(const ssg_conv_desc* d) {
   if (!d || validate(d) != SSG_OK) return 0;
-  if (ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d) || !uses_dma(d)) return 0;
+  if (ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d)) return 0;
+  const bool narrow_k32 = d->Cout <= 32 && d->w_split && split_bn(d) >= 1000;
+  if (!uses_dma(d) && !narrow_k32) return 0;
   const ConvArgs a = to_args(d);
   int th, tw;
   if (d->w_split && split_bn(d) > 0) {                          // split-operand kernels: 4 x 32-pixel halo tiles (also where fp32 takes <256,64>), 8 x 16 DMA tiles
@@ -362,6 +369,11 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
   if (d->ws && !d->bnpart) {                 // split-K only with a workspace of the size ssg_conv2d_workspace_bytes reports
     int k; const int64_t need = splitk_bytes(d, &k);
     if (need > 0 && d->ws_bytes >= need && !((uintptr_t)d->ws & 15)) { a.ws = d->ws; a.ksplit = k; }
+  }
+  if (d->Cout <= 32 && d->w_split && !d->parity_merge && split_bn(d) >= 1000) {   // narrow k32 tiles
+    SSG_REQUIRE(ssg_aligned16(d->w_split), SSG_EALIGN, "conv: w_split alignment");
+    a.w = (const float*)d->w_split; a.ws = nullptr; a.ksplit = 1;
+    return ssg_conv_igemm_halo_k32_launch(a, split_bn(d), st);
   }
   SSG_REQUIRE(!d->bnpart || uses_dma(d), SSG_EINVAL, "conv: bnpart given but this shape has no statistics epilogue (ssg_conv2d_bnpart_rows == 0)");
   SSG_REQUIRE(!d->parity_merge || (d->w_split && split_bn(d) == 64), SSG_EINVAL,

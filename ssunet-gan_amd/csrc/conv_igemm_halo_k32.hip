@@ -285,7 +285,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       for (int e = 0; e < MI * NI * 4; ++e) {
         const int i = e / (NI * 4), j = (e >> 2) % NI, r = e & 3;
         const int p = wm * WTM + i * 16 + l15;
-        scr[e * (NW * 64)] = ssg_conv_slow_value(as, n, ty * TH + (p >> 5), tx * TW + (p & 31), n0 + wn * WTN + j * 16 + kg * 4 + r, 0, 9);
+        const int co = n0 + wn * WTN + j * 16 + kg * 4 + r;
+        scr[e * (NW * 64)] = co < as.Cout ? ssg_conv_slow_value(as, n, ty * TH + (p >> 5), tx * TW + (p & 31), co, 0, 9) : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -318,8 +319,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn * WTN + j * 16 + kg * 4;
+    const bool cok = BN >= 64 || co < a.Cout;              // narrow tiles: padding columns (Cout % 4 == 0: whole quads)
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) bv = *(const f32x4*)(a.bias + co);
+    if (a.bias && cok) bv = *(const f32x4*)(a.bias + co);
     if (want_bn) {
       // Column sums for the batch-norm statistics: fp32 sums of DEVIATIONS from a pivot shared by the 16 lanes of a row group (the
       // group's first value of the column), converted to sums of the values in fp64 once per wave and column:
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      if (!pok[i]) continue;
+      if (!pok[i] || !cok) continue;
       f32x4 v = acc[i][j] + bv;
       if (a.res) v += *(const f32x4*)(a.res + opix[i] * a.ldr + co);
       if (a.act == SSG_ACT_RELU) {
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   }
   if (want_bn) {
     __syncthreads();
-    if (tid < BN) {
+    if (tid < BN && n0 + tid < a.Cout) {
       double t1 = 0, t2 = 0;
 #pragma unroll
       for (int k = 0; k < WAVES_M; ++k) { t1 += red[(k * 2 + 0) * BN + tid]; t2 += red[(k * 2 + 1) * BN + tid]; }
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 // lane l of fragment j holds output channel j*16 + (l & 15), channels chunk32*32 + (l >> 4)*8 .. +7.  One thread per (row, step, k-group).
 __global__ __launch_bounds__(256) void pack_split_k32_kernel(const float* __restrict__ w, int R, int Kp, int BN, unsigned char* __restrict__ out) {
   const int nsteps = Kp >> 5;                            // 32-channel steps
-  const long long total = (long long)(R / BN) * BN * nsteps * 4;
+  const long long total = (long long)((R + BN - 1) / BN) * BN * nsteps * 4;       // rows beyond R (narrow tiles): zero weights
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int g = (int)(i & 3);
     long long t = i >> 2;
@@ -389,7 +391,8 @@ __global__ __launch_bounds__(256) void pack_split_k32_kernel(const float* __rest
     const int chunk16 = chunk32 * 2 + (g >> 1);
     const float* src = w + (size_t)row * Kp + (size_t)(chunk16 * 9 + tap) * 16 + (g & 1) * 8;
     bf16x8 p1, p2, p3;
-    split3(*(const f32x4*)src, *(const f32x4*)(src + 4), p1, p2, p3);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    split3(row < R ? *(const f32x4*)src : z, row < R ? *(const f32x4*)(src + 4) : z, p1, p2, p3);
     const int j = rl >> 4, l = (rl & 15) + 16 * g;
     unsigned char* dst = out + ((size_t)tile * nsteps + s) * BN * 192 + (size_t)j * 3 * 1024 + (size_t)l * 16;
     *(bf16x8*)(dst) = p1; *(bf16x8*)(dst + 1024) = p2; *(bf16x8*)(dst + 2048) = p3;
@@ -405,10 +408,10 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   a.tiles_y = (a.GH + TH - 1) / TH;
   static const int swz = [] { const char* e = getenv("SSG_XCD_SWIZZLE"); return e ? atoi(e) : 1; }();
   a.xcd_swizzle = swz;
-  a.ntiles_n = a.Cout / BN;
+  a.ntiles_n = (a.Cout + BN - 1) / BN;                    // narrow tiles (BN 16 / 32): the last columns may be padding
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
   constexpr int lds_bytes = 3 * 4 * NPIX * 16 + 3 * BN * 192 + 1024;
-  static_assert(lds_bytes <= 160 * 1024 && (NW == 8 || lds_bytes <= 80 * 1024), "LDS budget");
+  static_assert(lds_bytes <= 160 * 1024 && (NW != 4 || BN <= 32 || lds_bytes <= 80 * 1024), "LDS budget");
   static const hipError_t attr = hipFuncSetAttribute((const void*)conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (attr != hipSuccess) { ssg_set_error("conv halo k32: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
@@ -446,6 +449,15 @@ int ssg_conv_halo_k32_fmt(const ConvArgs& a) {
   if ((a.ldo & 3) || ((uintptr_t)a.out & 15) || (a.res && ((a.ldr & 3) || ((uintptr_t)a.res & 15))) || (a.bias && ((uintptr_t)a.bias & 15))) return 0;
   const unsigned long long bytes = (unsigned long long)a.N * a.H * a.W * (unsigned long long)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4ull;
   if (bytes > 0xfffffff0ull) return 0;                  // 32-bit byte offsets of the buffer descriptors
+  if (a.Cout <= 32) {
+    // narrow layers (SPADE's x -> segmentation-map convs: 512 -> 16 at 128^2, 768 -> 24 at 64^2): 8 x 32-pixel tiles, all output
+    // channels in one 16- or 32-column tile, 256 threads.  Two LDS fragment reads per four MFMAs instead of one: the LDS pipe is the
+    // bound, at several times the rate of the fp32 256 x 32 register kernel these shapes ran on (41-44 TFLOP/s).
+    static const int narrow = [] { const char* e = getenv("SSG_K32_NARROW"); return e ? atoi(e) : 1; }();
+    const long long wgs = (long long)a.N * ((a.GH + 7) / 8) * ((a.GW + 31) / 32);
+    if (!narrow || a.Cout < 12 || (a.Cout & 3) || a.C1 + a.C2 < 128) return 0;
+    return (on == 2 || wgs >= 192) ? (a.Cout <= 16 ? 1016 : 1032) : 0;
+  }
   if (a.Cout % 128 == 0) {
     const long long wgs = (long long)a.N * ((a.GH + 7) / 8) * ((a.GW + 31) / 32) * (a.Cout / 128);
     const long long waves = (wgs + 255) / 256;
@@ -461,18 +473,20 @@ int ssg_conv_halo_k32_fmt(const ConvArgs& a) {
   return 0;
 }
 
-void ssg_conv_halo_k32_tile(int fmt, int* th, int* tw) { *tw = 32; *th = fmt == 1128 ? 8 : (fmt == 2064 ? 16 : 4); }
+void ssg_conv_halo_k32_tile(int fmt, int* th, int* tw) { *tw = 32; *th = (fmt == 1128 || fmt == 1016 || fmt == 1032) ? 8 : (fmt == 2064 ? 16 : 4); }
 
 int ssg_conv_igemm_halo_k32_launch(const ConvArgs& a, int fmt, hipStream_t st) {
   if (fmt == 1128) return launch<8, 128, 4, 2>(a, st);
   if (fmt == 1064) return launch<4, 64, 2, 2>(a, st);
   if (fmt == 2064) return launch<16, 64, 8, 1>(a, st);
+  if (fmt == 1016) return launch<8, 16, 4, 1>(a, st);
+  if (fmt == 1032) return launch<8, 32, 4, 1>(a, st);
   ssg_set_error("conv halo k32: unknown format %d", fmt);
   return SSG_EINVAL;
 }
 
 int ssg_pack_split_k32_launch(const float* w_packed, int R, int Kp, int BN, void* out, hipStream_t st) {
-  const long long total = (long long)(R / BN) * BN * (Kp >> 5) * 4;
+  const long long total = (long long)((R + BN - 1) / BN) * BN * (Kp >> 5) * 4;
   long long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(pack_split_k32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w_packed, R, Kp, BN, (unsigned char*)out);

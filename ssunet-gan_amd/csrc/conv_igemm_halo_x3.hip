@@ -616,18 +616,18 @@ int ssg_conv_igemm_halo_x3_launch(const ConvArgs& a, int variant, hipStream_t st
 }
 
 extern "C" int64_t ssg_pack_weights_split_bytes(int R, int Kp, int BN) {
-  if (BN == 1064 || BN == 1128) {                        // k32 format (conv_igemm_halo_k32.hip): whole tiles, whole 32-channel steps of 9 taps
+  if (BN == 1064 || BN == 1128 || BN == 1016 || BN == 1032) {   // k32 format (conv_igemm_halo_k32.hip): whole 32-channel steps of 9 taps; whole tiles (1016 / 1032: the one tile is padded with zero rows)
     const int bn = BN - 1000;
-    if (R <= 0 || R % bn || Kp <= 0 || Kp % (32 * 9)) return 0;
-    return (int64_t)(R / bn) * (Kp / 32) * bn * 192;
+    if (R <= 0 || (bn >= 64 && R % bn) || (bn < 64 && R > bn) || Kp <= 0 || Kp % (32 * 9)) return 0;
+    return (int64_t)((R + bn - 1) / bn) * (Kp / 32) * bn * 192;
   }
   if (R <= 0 || Kp <= 0 || Kp % 16 || (BN != 64 && BN != 128)) return 0;
   return (int64_t)((R + BN - 1) / BN) * (Kp / 16) * BN * XROW;
 }
 
 extern "C" int ssg_pack_weights_split_bf16x3(const float* w_packed, int R, int Kp, int BN, void* out, void* stream) {
-  if (BN == 1064 || BN == 1128) {
-    SSG_REQUIRE(w_packed && out && R > 0 && R % (BN - 1000) == 0 && Kp > 0 && Kp % (32 * 9) == 0, SSG_EINVAL, "pack_split k32: bad args");
+  if (BN == 1064 || BN == 1128 || BN == 1016 || BN == 1032) {
+    SSG_REQUIRE(w_packed && out && R > 0 && (BN >= 1064 ? R % (BN - 1000) == 0 : R <= BN - 1000) && Kp > 0 && Kp % (32 * 9) == 0, SSG_EINVAL, "pack_split k32: bad args");
     SSG_REQUIRE(ssg_aligned16(w_packed) && ssg_aligned16(out), SSG_EALIGN, "pack_split: 16-B alignment");
     return ssg_pack_split_k32_launch(w_packed, R, Kp, BN - 1000, out, (hipStream_t)stream);
   }

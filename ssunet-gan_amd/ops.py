@@ -319,7 +319,8 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
         if parity_merge:
             label = 'conv_igemm_halo_x3_kernel<128,64,4,1,true>'
         elif split is not None and bn >= 1000:
-            label = {1128: 'conv_halo_k32_kernel<8,128>', 1064: 'conv_halo_k32_kernel<4,64>', 2064: 'conv_halo_k32_kernel<16,64>'}[bn]
+            label = {1128: 'conv_halo_k32_kernel<8,128>', 1064: 'conv_halo_k32_kernel<4,64>', 2064: 'conv_halo_k32_kernel<16,64>',
+                     1016: 'conv_halo_k32_kernel<8,16>', 1032: 'conv_halo_k32_kernel<8,32>'}[bn]
         elif split is not None:
             if 'halo' in label:
                 label = label.replace('conv_igemm_halo_kernel', 'conv_igemm_halo_x3_kernel').replace('<256,64>', '<128,64>')

@@ -281,6 +281,59 @@ def _labels(ops, fn):
         ops.PROFILE = None
 
 
+# Narrow k32 tiles (<8,16> / <8,32>: all output channels of a 12..32-channel layer in one padded column tile; SPADE's x -> map convs):
+# same accuracy bound against fp64 as the fp32-MFMA kernel, bias + residual + activation epilogue, padded columns never written
+# (the output rows are checked beyond Cout), batch-norm partial rows, and the non-finite guard.
+@pytest.mark.parametrize('c1,c2,co,h,w,nb', [(512, 0, 16, 64, 64, 4), (256, 0, 24, 40, 72, 3), (128, 128, 32, 33, 50, 2), (128, 0, 12, 24, 40, 2)])
+def test_narrow_k32_tiles(pkg, dev, c1, c2, co, h, w, nb):
+    ops = pkg.ops
+    call = pkg._lib.call
+    torch.manual_seed(31)
+    torch.set_num_threads(16)
+    ci = c1 + c2
+    xc = torch.randn(nb, ci, h, w) * 1.5 + 0.3
+    wc = torch.randn(co, ci, 3, 3) / (3 * ci ** 0.5)
+    bc = torch.randn(co)
+    rc = torch.randn(nb, co, h, w)
+    ref = F.leaky_relu(F.conv2d(xc.double(), wc.double(), bc.double(), 1, 1) + rc.double(), 0.2)
+    x1 = ops.to_nhwc(xc[:, :c1].to(dev)); x2 = ops.to_nhwc(xc[:, c1:].to(dev)) if c2 else None
+    wd = wc.to(dev); bd = bc.to(dev); res = ops.to_nhwc(rc.to(dev))
+    from ssunet_gan_amd._lib import ACT_LRELU, ACT_NONE
+
+    def fwd():
+        out = ops.new_nhwc(nb, co, h, w, dev)
+        out.fill_(-7.0)                                       # also the padding between Cout and the pixel stride, if any
+        return ops._conv_fwd_impl(x1, x2, wd, bd, 1, 1, ACT_LRELU, 0.2, res=res, out=out)
+    call('ssg_conv_set_k32_mode', 2)
+    try:
+        y32 = _run(ops, False, fwd).cpu().double()
+        y3, labels = _labels(ops, lambda: _run(ops, True, fwd))
+        assert labels and ('k32_kernel<8,16>' if co <= 16 else 'k32_kernel<8,32>') in labels[0], labels
+        y3 = y3.cpu().double()
+        e32 = (y32 - ref).abs(); e3 = (y3 - ref).abs()
+        # the maximum over ~1e5 outputs is a noisy statistic (2.2 x on one of these shapes): 3 x on it, 2 x on the rms
+        assert e3.max().item() <= 3.0 * e32.max().item() + 1e-6, (e3.max().item(), e32.max().item())
+        assert e3.pow(2).mean().sqrt().item() <= 2.0 * e32.pow(2).mean().sqrt().item() + 1e-8
+        # batch-norm partial rows from the epilogue: column sums and sums of squares of the raw conv output
+        y, part = _run(ops, True, lambda: ops._conv_fwd_impl(x1, x2, wd, None, 1, 1, ACT_NONE, 0.0, want_bn=True))
+        assert part is not None and part.shape[1:] == (2, co)
+        yd = y.double()
+        s1 = yd.sum(dim=(0, 2, 3)).cpu(); s2 = (yd * yd).sum(dim=(0, 2, 3)).cpu()
+        tot = part.sum(0).cpu()
+        # fp32 deviation sums per 16-lane group, fp64 beyond: 1e-6 of the sum of squares
+        assert torch.allclose(tot[0], s1, rtol=1e-6, atol=1e-6 * s2.max().item() ** 0.5 * 64) and torch.allclose(tot[1], s2, rtol=1e-6, atol=1e-3)
+        # non-finite operands: the class of every output (finite value / +inf / -inf / NaN) is the fp32 kernel's
+        xb = _inject(xc.clone(), SPECIALS, 41)
+        xb1 = ops.to_nhwc(xb[:, :c1].to(dev)); xb2 = ops.to_nhwc(xb[:, c1:].to(dev)) if c2 else None
+        fnb = lambda: ops._conv_fwd_impl(xb1, xb2, wd, bd, 1, 1, ACT_NONE, 0.0)
+        want = _run(ops, False, fnb)
+        got, labels = _labels(ops, lambda: _run(ops, True, fnb))
+        assert any('k32' in l for l in labels), labels
+        _same_class(got, want, 'narrow tile, special activations')
+    finally:
+        call('ssg_conv_set_k32_mode', 1)
+
+
 @pytest.mark.parametrize('k32', [0, 2], ids=['x3', 'k32'])
 @pytest.mark.parametrize('c1,c2,co,h,w,nb', [(128, 0, 128, 128, 128, 4), (64, 64, 64, 48, 80, 2), (64, 0, 64, 64, 64, 3)])
 def test_split_conv_on_nonfinite_operands(pkg, dev, c1, c2, co, h, w, nb, k32):
