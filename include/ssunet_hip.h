@@ -85,6 +85,11 @@ typedef struct {
                              * out_sy = out_sx = 2, out_oy = out_ox = 0, no bias / res / bnpart, w_split for a 64-column tile.  Only
                              * where ssg_conv2d_split_bn(d) returns 64 for such a descriptor; otherwise the caller launches the classes
                              * one by one (parity_merge = 0, ntaps = 1 / 2 / 2 / 4, out_oy / out_ox = the class).  0 = plain conv. */
+  /* ABI 8: fused batch-norm apply on the INPUT (archs.py:229-230, relu(bn1(conv1(x))) feeding conv2): the launch convolves
+   * act_in(in1[p][c] * in_scale[c] + in_shift[c]) -- the tensor ssg_bn_apply_f32 would have written, same fp32 fma, never
+   * materialised; zero padding applies to the ACTIVATED tensor.  in_scale = NULL: off.  Only where ssg_conv2d_in_affine_ok(d)
+   * returns 1 (split-operand k32 kernels, one input pointer, C1 <= 512, in_act none / ReLU / leaky ReLU). */
+  const float* in_scale; const float* in_shift; int in_act; float in_slope;
 } ssg_conv_desc;
 
 /* fp32 convolution on the bf16 matrix pipe (3x3, unit stride; archs.py:210,212 and their input gradients, models_seg_gan.py:37-39
@@ -101,6 +106,7 @@ typedef struct {
  * tiles of 512 threads), reads the pack of 1064: pack with BN = 1064.  ssg_conv_set_k32_mode(0 / 1 / 2): never /
  * where the grid fills the chip (default, SSG_K32) / wherever the shape is legal (tests). */
 int ssg_conv2d_split_bn(const ssg_conv_desc* d);
+int ssg_conv2d_in_affine_ok(const ssg_conv_desc* d);   /* ABI 8: 1 when the launch for `d` (w_split set) takes in_scale / in_shift */
 int ssg_conv_set_k32_mode(int mode);
 int64_t ssg_pack_weights_split_bytes(int R, int Kp, int BN);
 int ssg_pack_weights_split_bf16x3(const float* w_packed, int R, int Kp, int BN, void* out, void* stream);
@@ -159,9 +165,13 @@ typedef struct {
   float* ws; int64_t ws_bytes;
   int flags;                /* bit 0: 3x3 stride-1 weight gradients multiply on the bf16 matrix pipe with both fp32 operands split into
                              * three bf16 terms (wgrad_halo_x3_kernel: fp32-class accuracy, see ssg_conv_desc.w_split); 0 = fp32 MFMA */
+  /* ABI 8: the x operand is act_in(in1 * in_scale[c] + in_shift[c]) (see ssg_conv_desc.in_scale): the weight gradient of a conv
+   * whose input was a fused batch-norm apply.  NULL = off; only where ssg_conv2d_wgrad_in_affine_ok(d) returns 1. */
+  const float* in_scale; const float* in_shift; int in_act; float in_slope;
 } ssg_wgrad_desc;
 
 int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d);
+int ssg_conv2d_wgrad_in_affine_ok(const ssg_wgrad_desc* d);   /* ABI 8 */
 int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream);
 /* 0..2 = wgrad_kernel<128,128>/<128,64>/<128,32>, 30/31 = wgrad_halo_kernel<32,128>/<64,64> (3x3 stride-1
  * window kept in LDS; default for those), 20/21 = wgrad_dma_kernel<128,128>/<128,64> (default

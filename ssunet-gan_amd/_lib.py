@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ('bnpart', C.c_void_p),
         ('ws', C.c_void_p), ('ws_bytes', C.c_int64),
         ('w_split', C.c_void_p), ('parity_merge', C.c_int),
+        ('in_scale', C.c_void_p), ('in_shift', C.c_void_p), ('in_act', C.c_int), ('in_slope', C.c_float),
     ]
 
 
@@ -52,6 +53,7 @@ class WgradDesc(C.Structure):
         ('dw_oihw', C.c_void_p),
         ('ws', C.c_void_p), ('ws_bytes', C.c_int64),
         ('flags', C.c_int),
+        ('in_scale', C.c_void_p), ('in_shift', C.c_void_p), ('in_act', C.c_int), ('in_slope', C.c_float),
     ]
 
 
@@ -75,6 +77,8 @@ SIGNATURES = {
     'ssg_conv2d_bnpart_rows': [C.POINTER(ConvDesc)],
     'ssg_conv2d_workspace_bytes': [C.POINTER(ConvDesc)],
     'ssg_conv2d_split_bn': [C.POINTER(ConvDesc)],
+    'ssg_conv2d_in_affine_ok': [C.POINTER(ConvDesc)],
+    'ssg_conv2d_wgrad_in_affine_ok': [C.POINTER(WgradDesc)],
     'ssg_pack_weights_split_bytes': [_I, _I, _I],
     'ssg_conv_set_k32_mode': [_I],
     'ssg_wgrad_set_k32_mode': [_I],
@@ -182,10 +186,10 @@ _RESTYPES = {
     'ssg_gemm_wgrad_bf16_workspace_bytes': C.c_int64,
     'ssg_bn_stats_from_partials_workspace_bytes': C.c_int64,
 }
-_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_split_bn', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
+_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_split_bn', 'ssg_conv2d_in_affine_ok', 'ssg_conv2d_wgrad_in_affine_ok', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
                                 'ssg_spade_conv_modulate_ok', 'ssg_se_gate_ok'}
 
-ABI_VERSION = 7          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
+ABI_VERSION = 8          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
 
 _lib = None
 

@@ -26,8 +26,22 @@ class _BasicBlockFn(torch.autograd.Function):
         x2 = to_nhwc(x2) if x2 is not None else None
         # batch-norm statistics ride the producing conv's epilogue where its kernel has one (part = None otherwise)
         c1, part1 = _conv_fwd_impl(x1, x2, w1, None, stride, 1, ACT_NONE, 0.0, want_bn=True)
-        y1, st1, cnt1 = _bn_fwd_impl(c1, g1, b1, rm1, rv1, None, eps1, mom1, ACT_RELU, 0.0, var_mode, group, part=part1)
-        c2, part2 = _conv_fwd_impl(y1, None, w2, None, 1, 1, ACT_NONE, 0.0, want_bn=True)
+        # relu(bn1(c1)) is applied on conv2's INPUT where its kernel can (the split-operand k32 tiles): y1 is never written, the
+        # backward's weight gradient reads c1 through the same transform and the ReLU mask is recomputed from c1 as before
+        y1 = None
+        c2 = None
+        if ops.BN_FUSE_INPUT and part1 is not None:
+            _, st1, cnt1 = _bn_fwd_impl(c1, g1, b1, rm1, rv1, None, eps1, mom1, ACT_RELU, 0.0, var_mode, group, part=part1, apply=False)
+            r = _conv_fwd_impl(c1, None, w2, None, 1, 1, ACT_NONE, 0.0, want_bn=True, in_affine=(st1[2], st1[3], ACT_RELU, 0.0))
+            if r is not None:
+                c2, part2 = r
+            else:
+                with ops._hbm('bn_fwd', 8.0 * c1.numel()):
+                    y1 = ops._bn_apply(c1, st1, None, ACT_RELU, 0.0)
+        else:
+            y1, st1, cnt1 = _bn_fwd_impl(c1, g1, b1, rm1, rv1, None, eps1, mom1, ACT_RELU, 0.0, var_mode, group, part=part1)
+        if c2 is None:
+            c2, part2 = _conv_fwd_impl(y1, None, w2, None, 1, 1, ACT_NONE, 0.0, want_bn=True)
         if wsc is not None:
             sc = _conv_fwd_impl(x1, x2, wsc, None, stride, 0, ACT_NONE, 0.0)
         else:
@@ -35,7 +49,7 @@ class _BasicBlockFn(torch.autograd.Function):
                 raise ValueError('identity shortcut with a two-tensor input')
             sc = x1
         out, st2, cnt2 = _bn_fwd_impl(c2, g2, b2, rm2, rv2, sc, eps2, mom2, ACT_RELU, 0.0, var_mode, group, part=part2)
-        ctx.save_for_backward(x1, x2, c1, y1, c2, out, w1, g1, w2, g2, wsc, st1, st2)
+        ctx.save_for_backward(x1, x2, c1, y1, c2, out, w1, g1, w2, g2, wsc, st1, st2)      # y1 = None on the fused route
         ctx.cfg = (stride, group, cnt1, cnt2)
         return out
 
@@ -50,8 +64,16 @@ class _BasicBlockFn(torch.autograd.Function):
         need_x1, need_x2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
         # bn2 backward; dres = dout masked by the final ReLU = gradient of the shortcut branch
         dc2, g, dg2, db2 = _bn_bwd_impl(c2, out, dout, g2, st2, ACT_RELU, 0.0, group, cnt2, want_dres=True)
-        dw2 = _conv_wgrad_impl(y1, None, dc2, w2.shape, 1, 1)
-        dy1 = _conv_dgrad_impl(dc2, w2, 1, 1, y1.shape[2], y1.shape[3], 0, y1.shape[1])
+        if y1 is None:                                   # fused route: conv2 read relu(bn1(c1)) through its input transform
+            dw2 = _conv_wgrad_impl(c1, None, dc2, w2.shape, 1, 1, in_affine=(st1[2], st1[3], ACT_RELU, 0.0))
+            if dw2 is None:                              # no weight-gradient kernel with the transform for this shape: write y1 now
+                with ops._hbm('bn_fwd', 8.0 * c1.numel()):
+                    y1w = ops._bn_apply(c1, st1, None, ACT_RELU, 0.0)
+                dw2 = _conv_wgrad_impl(y1w, None, dc2, w2.shape, 1, 1)
+                del y1w
+        else:
+            dw2 = _conv_wgrad_impl(y1, None, dc2, w2.shape, 1, 1)
+        dy1 = _conv_dgrad_impl(dc2, w2, 1, 1, c1.shape[2], c1.shape[3], 0, c1.shape[1])
         dc1, _, dg1, db1 = _bn_bwd_impl(c1, y1, dy1, g1, st1, ACT_RELU, 0.0, group, cnt1, want_dres=False, had_res=False)
         dw1 = _conv_wgrad_impl(x1, x2, dc1, w1.shape, stride, 1)
         dwsc = _conv_wgrad_impl(x1, x2, g, wsc.shape, stride, 0) if wsc is not None else None

@@ -293,6 +293,7 @@ ConvArgs to_args(const ssg_conv_desc* d) {
   a.ws = nullptr; a.ksplit = 1;
   a.parity = d->parity_merge;
   a.w32 = d->w;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_act = d->in_act; a.in_slope = d->in_slope;
   return a;
 }
 
@@ -350,9 +351,18 @@ static int64_t splitk_bytes(const ssg_conv_desc* d, int* ksplit) {
   return (int64_t)k * d->N * d->GH * d->GW * ((d->Cout + 3) & ~3) * (int64_t)sizeof(float);
 }
 
+extern "C" int ssg_conv2d_in_affine_ok(const ssg_conv_desc* d);
 extern "C" int ssg_conv2d_split_bn(const ssg_conv_desc* d) {
   if (!d || validate(d) != SSG_OK || ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d) || ssg_conv1x1_k64_ok(d)) return 0;
   return split_bn(d);
+}
+
+// 1 when the launch for `d` applies in_scale / in_shift / in_act to its input (ssg_conv_desc.in_scale)
+extern "C" int ssg_conv2d_in_affine_ok(const ssg_conv_desc* d) {
+  if (!d || validate(d) != SSG_OK || !d->w_split || d->parity_merge || d->Cout <= 32) return 0;
+  if (ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d) || ssg_conv1x1_k64_ok(d)) return 0;
+  const int fmt = split_bn(d);
+  return fmt >= 1000 && ssg_conv_halo_k32_in_affine_ok(to_args(d), fmt) ? 1 : 0;
 }
 
 extern "C" int64_t ssg_conv2d_workspace_bytes(const ssg_conv_desc* d) {
@@ -364,6 +374,8 @@ extern "C" int64_t ssg_conv2d_workspace_bytes(const ssg_conv_desc* d) {
 extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc != SSG_OK) return rc;
+  SSG_REQUIRE(!d->in_scale || (d->in_shift && ssg_conv2d_in_affine_ok(d)), SSG_EINVAL,
+              "conv: in_scale on a descriptor whose kernel has no fused input transform (ssg_conv2d_in_affine_ok == 0)");
   ConvArgs a = to_args(d);
   hipStream_t st = (hipStream_t)stream;
   if (d->ws && !d->bnpart) {                 // split-K only with a workspace of the size ssg_conv2d_workspace_bytes reports
@@ -418,6 +430,8 @@ extern "C" int ssg_conv2d_kernel_id(const ssg_conv_desc* d) {
 extern "C" int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream) {
   int rc = validate(d);
   if (rc != SSG_OK) return rc;
+  SSG_REQUIRE(!d->in_scale || (d->in_shift && ssg_conv2d_in_affine_ok(d)), SSG_EINVAL,
+              "conv: in_scale on a descriptor whose kernel has no fused input transform (ssg_conv2d_in_affine_ok == 0)");
   SSG_REQUIRE(!d->parity_merge || ssg_conv2d_split_bn(d) == 64, SSG_EINVAL,
               "conv: parity_merge on a descriptor that has no merged-parity kernel (ssg_conv2d_split_bn != 64)");
   if (d->parity_merge) return ssg_conv2d_igemm_f32(d, stream);

@@ -41,7 +41,12 @@ __device__ unsigned long long* ssg_probe_buf_k32 = nullptr;
 #define SSG_STAMP(i) do { } while (0)
 #endif
 
-template <int TH, int BN, int WAVES_M, int WAVES_N>
+// XF: the input is act(in1 * in_scale[c] + in_shift[c]) (ssg_conv_desc.in_scale: the batch-norm apply between conv1 and conv2 of a
+// residual block, never materialised): applied where a pixel chunk is split into its bf16 terms, constants from an LDS table
+// filled once per workgroup; halo pixels outside the image stay zero (the padding of the ACTIVATED tensor).
+constexpr int SSG_K32_XF_MAXC = 512;                     // <16, 64>: 154 KiB of image + ring leave 4 KiB for the table
+
+template <int TH, int BN, int WAVES_M, int WAVES_N, bool XF = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 1 : 2) void conv_halo_k32_kernel(const ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int TW = 32, BM = TH * TW;
@@ -64,6 +69,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   unsigned char* const img = lds;
   unsigned char* const ring = lds + IMG;
   unsigned char* const ldsDummy = ring + 3 * BSTG;       // 1 KiB: target of the dummy pieces
+  float* const xtab = (float*)(ldsDummy + 1024);         // XF: [2][C1] scale | shift
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,10 +135,21 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     }
   };
   bf16x8 cv[IPW][3];
-  auto convert_px = [&]() {
+  auto convert_px = [&](int chunk) {                     // chunk: the one whose loads sit in raw[]
 #pragma unroll
-    for (int k = 0; k < IPW; ++k)
-      split3(__builtin_bit_cast(f32x4, raw[2 * k]), __builtin_bit_cast(f32x4, raw[2 * k + 1]), cv[k][0], cv[k][1], cv[k][2]);
+    for (int k = 0; k < IPW; ++k) {
+      f32x4 lo = __builtin_bit_cast(f32x4, raw[2 * k]), hi = __builtin_bit_cast(f32x4, raw[2 * k + 1]);
+      if constexpr (XF) {
+        const int cb = (chunk < nchunks ? chunk : nchunks - 1) * 32 + (int)(px_kg[k] >> 2);      // this item's 8 channels (C2 == 0)
+        const f32x4 s0 = *(const f32x4*)(xtab + cb), s1 = *(const f32x4*)(xtab + cb + 4);
+        const f32x4 h0 = *(const f32x4*)(xtab + a.C1 + cb), h1 = *(const f32x4*)(xtab + a.C1 + cb + 4);
+        lo = lo * s0 + h0; hi = hi * s1 + h1;            // bn_apply_kernel's expression
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = ssg_act(lo[e], a.in_act, a.in_slope); hi[e] = ssg_act(hi[e], a.in_act, a.in_slope); }
+        if (px_pix[k] == OOB) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = lo; }
+      }
+      split3(lo, hi, cv[k][0], cv[k][1], cv[k][2]);
+    }
   };
   auto write_px = [&]() {
 #pragma unroll
@@ -174,8 +191,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   load_px(0);
   issue_b(0);
   issue_b(1);
+  if constexpr (XF) {
+    for (int i = tid; i < 2 * a.C1; i += NW * 64) xtab[i] = i < a.C1 ? a.in_scale[i] : a.in_shift[i - a.C1];
+    __syncthreads();
+  }
   wait_vmcnt<2 * B_PC>();
-  convert_px();
+  convert_px(0);
   write_px();
   SSG_STAMP(1);
 
@@ -257,8 +278,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #endif
         // <8, 128> lets the scheduler weave the ~130 conversion instructions into tap 8's MFMAs (they fit its registers); the other
         // two tiles pin them behind the last MFMA, where the fragments are dead (woven in, <4, 64> spilled 3 registers)
-        if (!(SSG_K32_CVT_FREE && TH == 8)) __builtin_amdgcn_sched_barrier(0);
-        convert_px();
+        if (!(SSG_K32_CVT_FREE && TH == 8 && !XF)) __builtin_amdgcn_sched_barrier(0);
+        convert_px(chunk + 1);
       }
     }
   }
@@ -286,7 +307,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         const int i = e / (NI * 4), j = (e >> 2) % NI, r = e & 3;
         const int p = wm * WTM + i * 16 + l15;
         const int co = n0 + wn * WTN + j * 16 + kg * 4 + r;
-        scr[e * (NW * 64)] = co < as.Cout ? ssg_conv_slow_value(as, n, ty * TH + (p >> 5), tx * TW + (p & 31), co, 0, 9) : 0.f;
+        scr[e * (NW * 64)] = co < as.Cout ? ssg_conv_slow_value<XF>(as, n, ty * TH + (p >> 5), tx * TW + (p & 31), co, 0, 9) : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -399,7 +420,7 @@ __global__ __launch_bounds__(256) void pack_split_k32_kernel(const float* __rest
   }
 }
 
-template <int TH, int BN, int WAVES_M, int WAVES_N>
+template <int TH, int BN, int WAVES_M, int WAVES_N, bool XF = false>
 int launch(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
   constexpr int NW = WAVES_M * WAVES_N;
@@ -412,10 +433,12 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
   constexpr int lds_bytes = 3 * 4 * NPIX * 16 + 3 * BN * 192 + 1024;
   static_assert(lds_bytes <= 160 * 1024 && (NW != 4 || BN <= 32 || lds_bytes <= 80 * 1024), "LDS budget");
-  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  constexpr int tab_bytes = XF ? 2 * SSG_K32_XF_MAXC * 4 : 0;       // scale | shift of up to SSG_K32_XF_MAXC input channels
+  static_assert(lds_bytes + tab_bytes <= 160 * 1024, "LDS budget with the input-transform table");
+  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N, XF>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes + tab_bytes);
   if (attr != hipSuccess) { ssg_set_error("conv halo k32: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
-  hipLaunchKernelGGL((conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N>), grid, dim3(NW * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N, XF>), grid, dim3(NW * 64), lds_bytes + (XF ? 2 * a.C1 * 4 : 0), st, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -475,7 +498,20 @@ int ssg_conv_halo_k32_fmt(const ConvArgs& a) {
 
 void ssg_conv_halo_k32_tile(int fmt, int* th, int* tw) { *tw = 32; *th = (fmt == 1128 || fmt == 1016 || fmt == 1032) ? 8 : (fmt == 2064 ? 16 : 4); }
 
+// fused input transform (ssg_conv_desc.in_scale): the three wide tiles, one input pointer, a table that fits beside the image
+bool ssg_conv_halo_k32_in_affine_ok(const ConvArgs& a, int fmt) {
+  if (fmt != 1128 && fmt != 1064 && fmt != 2064) return false;
+  if (a.C2 != 0 || a.C1 > SSG_K32_XF_MAXC) return false;
+  return a.in_act == SSG_ACT_NONE || a.in_act == SSG_ACT_RELU || a.in_act == SSG_ACT_LRELU;
+}
+
 int ssg_conv_igemm_halo_k32_launch(const ConvArgs& a, int fmt, hipStream_t st) {
+  if (a.in_scale) {
+    if (!a.in_shift || !ssg_conv_halo_k32_in_affine_ok(a, fmt)) { ssg_set_error("conv halo k32: in_scale on a launch without the fused input transform"); return SSG_EINVAL; }
+    if (fmt == 1128) return launch<8, 128, 4, 2, true>(a, st);
+    if (fmt == 1064) return launch<4, 64, 2, 2, true>(a, st);
+    return launch<16, 64, 8, 1, true>(a, st);
+  }
   if (fmt == 1128) return launch<8, 128, 4, 2>(a, st);
   if (fmt == 1064) return launch<4, 64, 2, 2>(a, st);
   if (fmt == 2064) return launch<16, 64, 8, 1>(a, st);

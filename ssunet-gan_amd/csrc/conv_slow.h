@@ -17,6 +17,9 @@ __device__ __forceinline__ bool ssg_nonfinite(float v) { return !(__builtin_fabs
 // One pre-epilogue accumulator value of a convolution launch: sum over taps [t_lo, t_hi) and all input channels of
 // in[n][gy*in_sy + dy_t][gx*in_sx + dx_t][c] * w32[co][k(t, c)], fp32 FMAs, out-of-image taps contribute nothing.
 // w32 = the fp32 packed weights [Cout][Kp] in kmode 0 (k = (c / 16 * ntaps + t) * 16 + c % 16).
+// XF: the launch carries a fused input transform (ssg_conv_desc.in_scale); a template parameter, not a run-time test of a.in_scale --
+// the test alone cost the k32 kernels 8 registers of their hot loops
+template <bool XF = false>
 __device__ inline float ssg_conv_slow_value(const ConvArgs& a, int n, int gy, int gx, int co, int t_lo, int t_hi) {
   if (co >= a.Cout) return 0.f;
   const float* wrow = a.w32 + (size_t)co * a.Kp;
@@ -31,6 +34,11 @@ __device__ inline float ssg_conv_slow_value(const ConvArgs& a, int n, int gy, in
     const size_t pix = inside ? (size_t)(n * a.H + iy) * a.W + ix : 0;
     for (int c = 0; c < Cin; c += 4) {
       f32x4 x = c < a.C1 ? *(const f32x4*)(a.in1 + pix * a.ld1 + c) : *(const f32x4*)(a.in2 + pix * a.ld2 + (c - a.C1));
+      if constexpr (XF) {                                // fused batch-norm apply on the input: bn_apply_kernel's arithmetic
+        x = x * *(const f32x4*)(a.in_scale + c) + *(const f32x4*)(a.in_shift + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = ssg_act(x[e], a.in_act, a.in_slope);
+      }
       if (!inside) x = f32x4{0.f, 0.f, 0.f, 0.f};
       const f32x4 w = *(const f32x4*)(wrow + ((c >> 4) * a.ntaps + t) * 16 + (c & 15));
       acc = __builtin_fmaf(x[0], w[0], acc); acc = __builtin_fmaf(x[1], w[1], acc);
@@ -76,11 +84,13 @@ __device__ __forceinline__ void ssg_slow_refill4(f32x4& acc, float* scr, int nth
 }
 
 // ---- weight gradients: one element dW[tap t][input channel c][output channel co] summed with fp32 FMAs over a workgroup's pixels
+template <bool XF = false>
 __device__ __forceinline__ float ssg_wgrad_slow_pixel(const WgArgs& a, int dyt, int dxt, int c, int co, int n, int gy, int gx, float acc) {
   const int iy = gy * a.in_sy + dyt, ix = gx * a.in_sx + dxt;
   const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;      // outside: a ZERO times dy (0 * inf = NaN, as the zero page of the fp32 kernels)
   const size_t pix = inside ? (size_t)(n * a.H + iy) * a.W + ix : 0;
   float x = c < a.C1 ? a.in1[pix * a.ld1 + c] : a.in2[pix * a.ld2 + (c - a.C1)];
+  if constexpr (XF) x = ssg_act(x * a.in_scale[c] + a.in_shift[c], a.in_act, a.in_slope);   // ssg_wgrad_desc.in_scale
   if (!inside) x = 0.f;
   return __builtin_fmaf(x, a.dout[((size_t)(n * a.GH + gy) * a.GW + gx) * a.ldd + co], acc);
 }
@@ -103,6 +113,7 @@ __device__ inline float ssg_wgrad_slow_value_flat(const WgArgs& a, int t, int c,
 
 // K-steps S0 <= S < S1 in column-strip order: S = (n * XB + strip) * GH + gy, a step = KPX pixels of row gy from column strip * KPX
 // (wgrad_halo_x3_kernel: KPX = 16; wgrad_k32_kernel: KPX = 32)
+template <bool XF = false>
 __device__ inline float ssg_wgrad_slow_value_strips(const WgArgs& a, int t, int c, int co, long long S0, long long S1, int KPX) {
   if (co >= a.Cout || c >= a.C1 + a.C2 || t >= a.ntaps) return 0.f;
   const int tb = (int)((a.tap_bits >> (6 * t)) & 63ull);
@@ -113,7 +124,7 @@ __device__ inline float ssg_wgrad_slow_value_strips(const WgArgs& a, int t, int 
     const int gy = (int)(S % a.GH); const long long col = S / a.GH;
     const int xb = (int)(col % XB), n = (int)(col / XB);
     const int gx1 = (xb + 1) * KPX < a.GW ? (xb + 1) * KPX : a.GW;
-    for (int gx = xb * KPX; gx < gx1; ++gx) acc = ssg_wgrad_slow_pixel(a, dyt, dxt, c, co, n, gy, gx, acc);
+    for (int gx = xb * KPX; gx < gx1; ++gx) acc = ssg_wgrad_slow_pixel<XF>(a, dyt, dxt, c, co, n, gy, gx, acc);
   }
   return acc;
 }

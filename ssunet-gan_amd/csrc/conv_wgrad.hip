@@ -321,9 +321,18 @@ extern "C" int64_t ssg_conv2d_wgrad_workspace_bytes(const ssg_wgrad_desc* d) {
   return (int64_t)p.splits * d->ntaps * (d->C1 + d->C2) * d->Cout * (int64_t)sizeof(float);
 }
 
+// the x operand as a fused batch-norm apply (ssg_wgrad_desc.in_scale): the k32 kernel only, one input pointer
+extern "C" int ssg_conv2d_wgrad_in_affine_ok(const ssg_wgrad_desc* d) {
+  if (!d || !d->in1 || !d->dout || wgrad4_kind(d)) return 0;     // asked before the workspace exists: no validate() here
+  if (d->C2 != 0 || (d->in_act != SSG_ACT_NONE && d->in_act != SSG_ACT_RELU && d->in_act != SSG_ACT_LRELU)) return 0;
+  return make_plan(d).halo == 2 ? 1 : 0;
+}
+
 extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   int rc = validate(d);
   if (rc != SSG_OK) return rc;
+  SSG_REQUIRE(!d->in_scale || (d->in_shift && ssg_conv2d_wgrad_in_affine_ok(d)), SSG_EINVAL,
+              "wgrad: in_scale on a descriptor whose kernel has no fused input transform (ssg_conv2d_wgrad_in_affine_ok == 0)");
   Plan p = make_plan(d);
   hipStream_t st = (hipStream_t)stream;
   const int w4 = wgrad4_kind(d);
@@ -335,6 +344,7 @@ extern "C" int ssg_conv2d_wgrad_f32(const ssg_wgrad_desc* d, void* stream) {
   a.tap_bits = 0;
   for (int t = 0; t < d->ntaps; ++t)
     a.tap_bits |= (unsigned long long)(((d->dy[t] + 2) & 7) | (((d->dx[t] + 2) & 7) << 3)) << (6 * t);
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_act = d->in_act; a.in_slope = d->in_slope;
   a.M = d->ntaps * (d->C1 + d->C2);
   a.Ptot = (long long)d->N * d->GH * d->GW;
   a.steps_per_split = p.steps_per_split;

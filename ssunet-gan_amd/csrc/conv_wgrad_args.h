@@ -10,6 +10,7 @@ struct WgArgs {
   long long Ptot;        // N*GH*GW
   int steps_per_split;   // K-steps (16 pixels each) per z-slice
   int xcd_swizzle;       // conv_wgrad_dma.hip: sharers of an operand on one XCD (set by the launcher)
+  const float* in_scale; const float* in_shift; int in_act; float in_slope;   // ssg_wgrad_desc.in_scale (conv_wgrad_k32.hip)
 };
 
 

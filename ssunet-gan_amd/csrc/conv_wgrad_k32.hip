@@ -45,6 +45,10 @@ constexpr int CB = 64, BN = 64;
 // 16-byte chunk c (0..7) of pixel row p sits at chunk position c ^ sw(p)
 __device__ __forceinline__ int sw(int p) { return ((((p >> 1) & 1) | (((p >> 3) & 1) << 1)) << 1); }
 
+// XF: the x operand is act(x * in_scale[c] + in_shift[c]) (ssg_wgrad_desc.in_scale: a batch-norm apply that was never materialised),
+// applied to a staged element on its way into LDS; a thread stages the same 8 channels for the whole launch, so its constants
+// are 16 registers loaded once.  Window pixels outside the image stay zero (the padding of the ACTIVATED tensor).
+template <bool XF>
 __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   unsigned char* const ximg = lds;
@@ -80,6 +84,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
   const int d_dst = di_px * 128 + ((di_c ^ sw(di_px)) << 4);
 
   struct Raw { u32x4 lo, hi; };
+  float* const xtab = (float*)(lds + XIMG + DIMG);        // XF: scale[64] | shift[64] of this workgroup's input channels
+  if constexpr (XF) {                                    // C2 == 0 (ssg_conv2d_wgrad_in_affine_ok); visible after the first segment's barrier
+    if (tid < 128) xtab[tid] = tid < 64 ? a.in_scale[c0 + tid] : a.in_shift[c0 + tid - 64];
+  }
   auto load_x = [&](int n, int row, int gx0) -> Raw {    // window row `row` (may be -1 or H: zeros), columns gx0 - 1 .. gx0 + 32
     const int ix = gx0 - 1 + xi_px;
     const bool ok = has_x && (unsigned)row < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
@@ -98,10 +106,22 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
     r.hi = __builtin_amdgcn_raw_buffer_load_b128(d_rs, ok ? vo + 16u : OOB, 0, 0);
     return r;
   };
-  auto store_x = [&](const Raw& r, int slot) {
+  auto x_inside = [&](int row, int gx0) -> bool {        // XF: is this thread's window pixel of row `row` inside the image
+    return (unsigned)row < (unsigned)a.H && (unsigned)(gx0 - 1 + xi_px) < (unsigned)a.W;
+  };
+  auto store_x = [&](const Raw& r, int slot, bool inside) {
     if (has_x) {
       bf16x8 p1, p2, p3;
-      split3(__builtin_bit_cast(f32x4, r.lo), __builtin_bit_cast(f32x4, r.hi), p1, p2, p3);
+      f32x4 lo = __builtin_bit_cast(f32x4, r.lo), hi = __builtin_bit_cast(f32x4, r.hi);
+      if constexpr (XF) {
+        const f32x4 s0 = *(const f32x4*)(xtab + 8 * xi_c), s1 = *(const f32x4*)(xtab + 8 * xi_c + 4);
+        const f32x4 h0 = *(const f32x4*)(xtab + 64 + 8 * xi_c), h1 = *(const f32x4*)(xtab + 64 + 8 * xi_c + 4);
+        lo = lo * s0 + h0; hi = hi * s1 + h1;                             // bn_apply_kernel's expression
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = ssg_act(lo[e], a.in_act, a.in_slope); hi[e] = ssg_act(hi[e], a.in_act, a.in_slope); }
+        if (!inside) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = lo; }
+      }
+      split3(lo, hi, p1, p2, p3);
       unsigned char* d = ximg + slot * XSLOT + x_dst;
       *(bf16x8*)d = p1; *(bf16x8*)(d + XPLANE) = p2; *(bf16x8*)(d + 2 * XPLANE) = p3;
     }
@@ -165,7 +185,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
     asm volatile("" ::: "memory");
     {
       const Raw r0 = load_x(n, ga - 1, gx0), r1 = load_x(n, ga, gx0), r2 = load_x(n, ga + 1, gx0), r3 = load_d(n, ga, gx0);   // all in flight together
-      store_x(r0, (ga + 0) & 3); store_x(r1, (ga + 1) & 3); store_x(r2, (ga + 2) & 3); store_d(r3, ga & 1);
+      store_x(r0, (ga + 0) & 3, XF ? x_inside(ga - 1, gx0) : true); store_x(r1, (ga + 1) & 3, XF ? x_inside(ga, gx0) : true);
+      store_x(r2, (ga + 2) & 3, XF ? x_inside(ga + 1, gx0) : true); store_d(r3, ga & 1);
     }
 
     for (int gy = ga; gy < gb; ++gy) {
@@ -214,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
       }
       if (more) {
         __builtin_amdgcn_sched_barrier(0);
-        store_x(nx, (gy + 3) & 3);                       // row gy + 2
+        store_x(nx, (gy + 3) & 3, XF ? x_inside(gy + 2, gx0) : true);      // row gy + 2
         store_d(nd, (gy + 1) & 1);
       }
       if (FLUSH > 0 && ++since == FLUSH) {
@@ -248,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           ssg_slow_refill4(tot[t][j], (float*)lds + tid, 512, [&](int r) {
-            return ssg_wgrad_slow_value_strips(as, t, c0 + wm * 16 + l15, n0 + (2 * wn + j) * 16 + 4 * g + r, S0, S1, KP);
+            return ssg_wgrad_slow_value_strips<XF>(as, t, c0 + wm * 16 + l15, n0 + (2 * wn + j) * 16 + 4 * g + r, S0, S1, KP);
           });
     }
   }
@@ -294,9 +315,11 @@ long long ssg_wgrad_k32_steps(const ssg_wgrad_desc* d) { return (long long)d->N 
 
 int ssg_wgrad_k32_launch(const WgArgs& a, dim3 grid, hipStream_t st) {
   constexpr int lds_bytes = XIMG + DIMG;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_k32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  if (attr != hipSuccess) { ssg_set_error("wgrad k32: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
-  hipLaunchKernelGGL(wgrad_k32_kernel, grid, dim3(512), lds_bytes, st, a);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_k32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  static const hipError_t attr_xf = hipFuncSetAttribute((const void*)wgrad_k32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes + 512);
+  if (attr != hipSuccess || attr_xf != hipSuccess) { ssg_set_error("wgrad k32: LDS attribute: %s", hipGetErrorString(attr != hipSuccess ? attr : attr_xf)); return (int)(attr != hipSuccess ? attr : attr_xf); }
+  if (a.in_scale) hipLaunchKernelGGL(wgrad_k32_kernel<true>, grid, dim3(512), lds_bytes + 512, st, a);
+  else hipLaunchKernelGGL(wgrad_k32_kernel<false>, grid, dim3(512), lds_bytes, st, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }

@@ -262,12 +262,17 @@ class _Timed(object):
             PROFILE.append((self.label, self.flops, self.e0, self.e1, self.tag))
 
 
+_DECLINED = object()      # _conv_launch: the library has no kernel with the fused input transform for this launch (nothing was launched)
+
+
 def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps, n, h, w, gh, gw, oh, ow,
-                 in_s, out_s, out_oy, out_ox, out, want_bn=False, tag=None, parity_merge=False):
+                 in_s, out_s, out_oy, out_ox, out, want_bn=False, tag=None, parity_merge=False, in_affine=None):
     """Returns None, or -- with want_bn and a kernel that has the statistics epilogue -- the fp64 tensor [rows, 2, cout] of
     per-tile (sum, sum of squares) of the conv output (ssg_conv_desc.bnpart).  parity_merge: the nine taps are the four parity
     classes of a 3x3 stride-2 input gradient (ssg_conv_desc.parity_merge); returns False, with nothing launched, when the library
-    has no merged kernel for this shape."""
+    has no merged kernel for this shape.  in_affine = (scale[C1], shift[C1], act, slope): the launch convolves act(x1 * scale +
+    shift) (ssg_conv_desc.in_scale: a batch-norm apply that is never materialised); returns _DECLINED, with nothing launched, when
+    the kernel this shape maps to has no such transform."""
     d = ConvDesc()
     d.in1 = x1.data_ptr(); d.C1 = pad4(x1.shape[1]); d.ld1 = _ld(x1)
     if x2 is not None:
@@ -292,6 +297,7 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     d.ws = None; d.ws_bytes = 0
     d.w_split = None
     d.parity_merge = 1 if parity_merge else 0
+    d.in_scale = None; d.in_shift = None; d.in_act = ACT_NONE; d.in_slope = 0.0
     split = None
     if parity_merge and not (MFMA_SPLIT and kmode == 0 and call('ssg_conv2d_split_bn', C.byref(d)) == 64):
         return False
@@ -300,6 +306,10 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
         if bn:
             split = _split_pack(wpk, row0, cout, kp, 1064 if bn == 2064 else bn)      # 2064: the 16-row tile reads the 64-column k32 pack
             d.w_split = split.data_ptr()
+    if in_affine is not None:
+        d.in_scale = in_affine[0].data_ptr(); d.in_shift = in_affine[1].data_ptr(); d.in_act = int(in_affine[2]); d.in_slope = float(in_affine[3])
+        if split is None or not call('ssg_conv2d_in_affine_ok', C.byref(d)):
+            return _DECLINED
     part = None
     if want_bn and BN_EPILOGUE:
         rows = call('ssg_conv2d_bnpart_rows', C.byref(d))
@@ -340,6 +350,11 @@ BN_EPILOGUE = _os.environ.get('SSG_BN_EPILOGUE', '1') != '0'
 # three bf16 terms (csrc/conv_igemm_halo_x3.hip: the error against fp64 is that of the fp32-MFMA kernel, tests/test_split_gpu.py;
 # 16/6 of the fp32 MFMA rate).  SSG_MFMA_SPLIT=0 keeps them on v_mfma_f32_32x32x2_f32 (conv_igemm_halo.hip).
 MFMA_SPLIT = _os.environ.get('SSG_MFMA_SPLIT', '1') == '1'
+# SSG_BN_FUSE_INPUT=1: relu(bn1(conv1(x))) of a residual block is applied on conv2's input (and on the x operand of conv2's weight
+# gradient) instead of being written out -- same bits (tests/test_blocks_gpu.py), one activation less to keep, 1.0 ms less in the
+# batch-norm passes of the 16 x 512^2 step and 1.0-2.5 ms MORE in the k32 kernels that take the transform (issue-bound: the extra
+# vector work on the operand path is not hidden), same-box A/B 195.5-195.9 vs 195.8-197.4 ms.  Off by default.
+BN_FUSE_INPUT = _os.environ.get('SSG_BN_FUSE_INPUT', '0') == '1'
 # SSG_PARITY_MERGE=0: the input gradient of a 3x3 stride-2 conv as four launches (one per output parity class) again
 PARITY_MERGE = _os.environ.get('SSG_PARITY_MERGE', '1') != '0'
 
@@ -373,9 +388,10 @@ def _out_hw(h, w, kh, kw, s, pad):
     return (h + pt + pb - kh) // s + 1, (w + pl + pr - kw) // s + 1
 
 
-def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=None, wscale=None, want_bn=False):
+def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=None, wscale=None, want_bn=False, in_affine=None):
     """Returns y, or (y, part) with want_bn: part = per-tile batch-norm partial sums of y from the conv epilogue, or None when
-    the kernel this shape maps to has none (the batch norm then runs its own statistics pass)."""
+    the kernel this shape maps to has none (the batch norm then runs its own statistics pass).  in_affine: see _conv_launch; the
+    result is None (nothing launched) when the library declines."""
     o, i, kh, kw = weight.shape
     n, c1, h, w = x1.shape
     c2 = x2.shape[1] if x2 is not None else 0
@@ -391,7 +407,9 @@ def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=
         out = new_nhwc(n, o, oh, ow, x1.device)
     part = _conv_launch(x1, x2, wpk, kp, kmode, 0, o, bias, res, act, slope, taps, n, h, w, oh, ow, oh, ow, stride, 1, 0, 0, out,
                         want_bn=want_bn and res is None and act == ACT_NONE,
-                        tag=_ROLE[0] if (kh == 3 and kw == 3 and _ROLE[0] is not None) else None)
+                        tag=_ROLE[0] if (kh == 3 and kw == 3 and _ROLE[0] is not None) else None, in_affine=in_affine)
+    if part is _DECLINED:
+        return None
     return (out, part) if want_bn else out
 
 
@@ -440,7 +458,9 @@ def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None, wscale
     return dx
 
 
-def _conv_wgrad_impl(x1, x2, dy, weight_shape, stride, pad):
+def _conv_wgrad_impl(x1, x2, dy, weight_shape, stride, pad, in_affine=None):
+    """in_affine = (scale, shift, act, slope): the x operand is act(x1 * scale + shift) (ssg_wgrad_desc.in_scale); returns None,
+    with nothing launched, when the kernel this shape maps to has no such transform."""
     o, i, kh, kw = weight_shape
     n, c1, h, w = x1.shape
     _, _, oh, ow = dy.shape
@@ -462,6 +482,11 @@ def _conv_wgrad_impl(x1, x2, dy, weight_shape, stride, pad):
     d.dw_oihw = dw.data_ptr()
     d.ws = None; d.ws_bytes = 0
     d.flags = 1 if MFMA_SPLIT else 0
+    d.in_scale = None; d.in_shift = None; d.in_act = ACT_NONE; d.in_slope = 0.0
+    if in_affine is not None:
+        d.in_scale = in_affine[0].data_ptr(); d.in_shift = in_affine[1].data_ptr(); d.in_act = int(in_affine[2]); d.in_slope = float(in_affine[3])
+        if not call('ssg_conv2d_wgrad_in_affine_ok', C.byref(d)):
+            return None
     nbytes = call('ssg_conv2d_wgrad_workspace_bytes', C.byref(d))
     ws = _ws(nbytes, dy.device)
     d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 8
@@ -642,16 +667,27 @@ def bn_fin(weight, bias, eps, momentum, var_mode, running_mean, running_var, sta
     return f
 
 
-def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part=None):
+def _bn_fwd_impl(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part=None, apply=True):
     """Timed wrapper (bench.py `hbm_stages`): algorithmic bytes per SURVEY.md 8(d) -- 2 reads + 1 write of the tensor, one read
     less when the statistics rode the producing conv's epilogue, one more for a residual."""
     n, c, h, w = x.shape
     reads = (1 if (part is not None and part.numel() > 0) else 2) + (1 if res is not None else 0)
-    with _hbm('bn_fwd', 4.0 * n * h * w * c * (reads + 1)):
-        return _bn_fwd_body(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part)
+    if not apply:                 # statistics only (the consumer conv applies scale / shift / act on its input): no pass over x at all
+        reads -= 1
+    with _hbm('bn_fwd', 4.0 * n * h * w * c * (reads + (1 if apply else 0))):
+        return _bn_fwd_body(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part, apply)
 
 
-def _bn_fwd_body(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part=None):
+def _bn_apply(x, stats, res, act, slope):
+    """y = act(x * scale + shift (+ res)) with the finalized statistics rows [mean, invstd, scale, shift]."""
+    n, c, h, w = x.shape
+    y = new_nhwc(n, c, h, w, x.device)
+    call('ssg_bn_apply_f32', ptr(x), n * h * w, c, _ld(x), ptr(stats[2]), ptr(stats[3]), ptr(res), _ld(res) if res is not None else 0,
+         act, slope, ptr(y), _ld(y), stream_ptr())
+    return y
+
+
+def _bn_fwd_body(x, weight, bias, running_mean, running_var, res, eps, momentum, act, slope, var_mode, group, part=None, apply=True):
     """stats -> (all-reduce) -> finalize -> apply.  Returns (y, stats[4,C], count): `count` is None for a local batch norm
     and, when synchronised, the fp64[1] device tensor holding the all-reduced pixel count (ranks may hold unequal batches:
     the count travels with the sums instead of being assumed to be p * world)."""
@@ -692,9 +728,7 @@ def _bn_fwd_body(x, weight, bias, running_mean, running_var, res, eps, momentum,
              ptr(running_mean), ptr(running_var), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), stream_ptr())
     if running_mean is not None or running_var is not None:
         _STATS_EPOCH[0] += 1
-    y = new_nhwc(n, c, h, w, dev)
-    call('ssg_bn_apply_f32', ptr(x), p, c, _ld(x), ptr(stats[2]), ptr(stats[3]), ptr(res), _ld(res) if res is not None else 0,
-         act, slope, ptr(y), _ld(y), stream_ptr())
+    y = _bn_apply(x, stats, res, act, slope) if apply else None
     return y, stats, (sums[2 * c:] if synced else None)
 
 
