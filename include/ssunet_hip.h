@@ -220,6 +220,20 @@ int64_t ssg_gemm_wgrad_bf16_workspace_bytes(int64_t P, int M, int N);
 int ssg_gemm_wgrad_bf16(const void* dy, int ldd, const void* x, int ldx, int64_t P, int M, int N, float* dw,
                         void* ws, int64_t ws_bytes, void* stream);
 
+/* bf16 dense k x k conv of a <= 4-channel image (the EfficientNet stem, efficientnet_pytorch/model.py:162,206: 3 -> 32..48, k = 3, s = 2,
+ * TF-SAME padding utils.py:123-146): SURVEY.md 8(b) `conv2d_{fwd,dgrad,wgrad}_nhwc_bf16`, k = 3.  x: fp32 NHWC image with 4-channel pixel
+ * rows (the model input); image values and weights are rounded to bf16 before they multiply, fp32 accumulation, bf16 output [N, OH, OW, Cout]
+ * (Cout % 8 == 0).  w_oihw / dw_oihw: fp32 [Cout][Cin][KH][KW].  wgrad: ws of ssg_conv2d_thin_bf16_wgrad_workspace_bytes bytes.
+ * dgrad writes the fp32 image gradient [N, H, W, 4] (channels >= Cin: zeros). */
+int ssg_conv2d_thin_bf16(const float* x, int N, int H, int W, int ldx, const float* w_oihw, int Cout, int Cin, int KH, int KW,
+                         int stride, int pad_t, int pad_l, int OH, int OW, void* y, int ldy, void* stream);
+int64_t ssg_conv2d_thin_bf16_wgrad_workspace_bytes(int N, int OH, int OW, int Cout, int KH, int KW);
+int ssg_conv2d_thin_bf16_wgrad(const float* x, int N, int H, int W, int ldx, const void* dy, int lddy, int Cout, int Cin,
+                               int KH, int KW, int stride, int pad_t, int pad_l, int OH, int OW, float* dw_oihw, void* ws,
+                               void* stream);
+int ssg_conv2d_thin_bf16_dgrad(const void* dy, int lddy, int N, int H, int W, const float* w_oihw, int Cout, int Cin, int KH, int KW,
+                               int stride, int pad_t, int pad_l, int OH, int OW, float* dx, int lddx, void* stream);
+
 /* bf16 twins of the HBM-bound kernels the MBConv block needs (same arguments and arithmetic as their _f32 namesakes below:
  * tensors are bf16 in HBM, arithmetic is fp32 in registers, statistics fp64; C % 4 == 0, 8-byte loads per lane).
  * Batch norm with act = SSG_ACT_SWISH fuses `swish(bn(x))` (model.py:75,80) into the apply pass; its backward recomputes the

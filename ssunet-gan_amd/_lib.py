@@ -76,6 +76,10 @@ SIGNATURES = {
     'ssg_conv2d_kernel_id': [C.POINTER(ConvDesc)],
     'ssg_conv2d_bnpart_rows': [C.POINTER(ConvDesc)],
     'ssg_conv2d_workspace_bytes': [C.POINTER(ConvDesc)],
+    'ssg_conv2d_thin_bf16': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    'ssg_conv2d_thin_bf16_wgrad_workspace_bytes': [_I, _I, _I, _I, _I, _I],
+    'ssg_conv2d_thin_bf16_wgrad': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    'ssg_conv2d_thin_bf16_dgrad': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'ssg_conv2d_split_bn': [C.POINTER(ConvDesc)],
     'ssg_conv2d_in_affine_ok': [C.POINTER(ConvDesc)],
     'ssg_conv2d_wgrad_in_affine_ok': [C.POINTER(WgradDesc)],
@@ -184,6 +188,7 @@ _RESTYPES = {
     'ssg_linear_fwd_workspace_bytes': C.c_int64,
     'ssg_sample_channel_sum_workspace_bytes': C.c_int64,
     'ssg_gemm_wgrad_bf16_workspace_bytes': C.c_int64,
+    'ssg_conv2d_thin_bf16_wgrad_workspace_bytes': C.c_int64,
     'ssg_bn_stats_from_partials_workspace_bytes': C.c_int64,
 }
 _NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_split_bn', 'ssg_conv2d_in_affine_ok', 'ssg_conv2d_wgrad_in_affine_ok', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',

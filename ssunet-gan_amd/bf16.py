@@ -95,6 +95,53 @@ def to_f32(x):
     return _ToF32.apply(x) if x.requires_grad else _to_f32_impl(x)
 
 
+# ----------------------------------------------------------------------------- dense k x k conv of the image (the stem)
+class _ConvThin(torch.autograd.Function):
+    """Conv2d(Cin <= 4 -> Cout, k x k, stride 1 / 2, no bias) of the fp32 input image into a bf16 tensor (model.py:162,206: the stem;
+    csrc/conv_stem_bf16.hip): operands rounded to bf16, fp32 accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        x = ops.to_nhwc(x)
+        n, cin, h, w = x.shape
+        o, i, kh, kw = weight.shape
+        if i != cin or cin > 4 or o % 8:
+            raise ValueError('conv_thin: needs Cin <= 4 and Cout %% 8 == 0 (weight %s, input channels %d)' % (tuple(weight.shape), cin))
+        pt, pb, pl, pr = ops._pad4(pad)
+        oh, ow = ops._out_hw(h, w, kh, kw, stride, pad)
+        y = new_bf16(n, o, oh, ow, x.device)
+        wc = weight.detach().contiguous()
+        call('ssg_conv2d_thin_bf16', ptr(x), n, h, w, ops._ld(x), ptr(wc), o, cin, kh, kw, stride, pt, pl, oh, ow, ptr(y), o, stream_ptr())
+        ctx.save_for_backward(x, wc)
+        ctx.cfg = (stride, pt, pl, oh, ow)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, wc = ctx.saved_tensors
+        stride, pt, pl, oh, ow = ctx.cfg
+        dy = as_bf16(dy)
+        n, cin, h, w = x.shape
+        o, _, kh, kw = wc.shape
+        dw = dx = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(wc)
+            ws = ops._ws(call('ssg_conv2d_thin_bf16_wgrad_workspace_bytes', n, oh, ow, o, kh, kw), x.device)
+            call('ssg_conv2d_thin_bf16_wgrad', ptr(x), n, h, w, ops._ld(x), ptr(dy), o, o, cin, kh, kw, stride, pt, pl, oh, ow, ptr(dw), ptr(ws),
+                 stream_ptr())
+        if ctx.needs_input_grad[0]:
+            dx = ops.new_nhwc(n, cin, h, w, x.device)
+            call('ssg_conv2d_thin_bf16_dgrad', ptr(dy), o, n, h, w, ptr(wc), o, cin, kh, kw, stride, pt, pl, oh, ow, ptr(dx), ops._ld(dx), stream_ptr())
+        return dx, dw, None, None
+
+
+def conv_thin(x, weight, stride=1, pad=0):
+    """Dense conv of a <= 4-channel fp32 image into the bf16 family (the EfficientNet stem)."""
+    _lib.require_gpu(x)
+    return _ConvThin.apply(x, weight, int(stride), pad)
+
+
 # ----------------------------------------------------------------------------- pointwise conv = GEMM on the bf16 MFMA
 def _pack(weight, transpose):
     """fp32 [O, I, 1, 1] parameter -> bf16 [rows_pad][Kp] operand (cached on the parameter like ops._pack)."""

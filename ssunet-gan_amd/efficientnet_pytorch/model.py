@@ -1,5 +1,7 @@
 """MBConvBlock and the EfficientNet feature extractor on the HIP kernels (mirrors
 efficientnet_pytorch/model.py:18-99,132-218 of the reference; parameter names and creation order kept)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -7,6 +9,10 @@ from .. import bf16, ops
 from .._lib import ACT_SWISH
 from .utils import (MemoryEfficientSwish, Swish, drop_connect, get_model_params, get_same_padding_conv2d, round_filters,
                     round_repeats)
+
+
+# SSG_BF16_STEM=0: in bf16 mode the stem stays an fp32 conv + fp32 batch norm followed by a conversion (rounds 2-3)
+BF16_STEM = os.environ.get('SSG_BF16_STEM', '1') != '0'
 
 
 class MBConvBlock(nn.Module):
@@ -148,10 +154,15 @@ class EfficientNet(nn.Module):
         return self
 
     def extract_features(self, inputs):
-        x = ops.batch_norm_act(self._conv_stem(ops.as_nhwc(inputs)), self._bn0, act=ACT_SWISH)
         lowp = getattr(self, '_ssg_dtype', torch.float32) == torch.bfloat16
-        if lowp:
-            x = bf16.to_bf16(x)
+        stem = self._conv_stem
+        if lowp and BF16_STEM and stem.bias is None and stem.out_channels % 8 == 0:
+            # the stem in the bf16 family too (csrc/conv_stem_bf16.hip): bf16-rounded image and weights, fp32 accumulation, bf16 output
+            x = bf16.batch_norm_act(bf16.conv_thin(ops.as_nhwc(inputs), stem.weight, stem.stride[0], stem.static_pad), self._bn0, act=ACT_SWISH)
+        else:
+            x = ops.batch_norm_act(stem(ops.as_nhwc(inputs)), self._bn0, act=ACT_SWISH)
+            if lowp:
+                x = bf16.to_bf16(x)
         for idx, block in enumerate(self._blocks):
             rate = self._global_params.drop_connect_rate
             if rate:

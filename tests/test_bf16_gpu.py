@@ -115,6 +115,35 @@ def test_mbconv_block_bf16(pkg, dev, tag):
     bufs = np.stack([_digest(b.float()) for b in m.buffers()])
     assert np.allclose(bufs[:, 1], gold[tag + '_bufs'][:, 1], rtol=2e-2, atol=1e-3)
 
+@pytest.mark.parametrize('n,cin,h,w,co,k,stride,pad', [(2, 3, 37, 50, 32, 3, 2, (0, 1, 0, 1)), (1, 3, 64, 64, 48, 3, 1, 1),
+                                                       (3, 3, 31, 29, 48, 3, 2, (1, 1, 1, 1)), (1, 4, 20, 24, 40, 5, 2, (1, 2, 1, 2))])
+def test_stem_conv_bf16(pkg, dev, n, cin, h, w, co, k, stride, pad):
+    """The bf16 dense k x k conv of the image (SURVEY.md 8(b) conv2d_{fwd,dgrad,wgrad}_nhwc_bf16, k = 3: the EfficientNet stem,
+    model.py:162,206 with utils.py:123-146's one-sided SAME padding): against fp64 F.conv2d on the bf16-ROUNDED operands -- forward
+    within the rounding of its bf16 output, weight and image gradients within fp32 accumulation of the same rounded operands."""
+    import torch.nn.functional as F
+    bf = pkg.bf16
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(co, cin, k, k, generator=g) / (k * cin ** 0.5)
+    pt, pb, pl, pr = pkg.ops._pad4(pad)
+    xr = x.bfloat16().double(); wr = wt.bfloat16().double()
+    ref = F.conv2d(F.pad(xr, (pl, pr, pt, pb)), wr, None, stride)
+    xd = x.to(dev).requires_grad_(True); wd = wt.to(dev).requires_grad_(True)
+    y = bf.conv_thin(xd, wd, stride, pad)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == tuple(ref.shape)
+    err = (y.double().cpu() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-6).all(), err.max().item()
+    dy = torch.randn(ref.shape, generator=g).bfloat16()
+    y.backward(dy.to(dev))
+    xp = F.pad(xr, (pl, pr, pt, pb)).requires_grad_(True); wp = wr.clone().requires_grad_(True)
+    F.conv2d(xp, wp, None, stride).backward(dy.double())
+    dwr = wp.grad
+    dxr = xp.grad[:, :, pt:pt + h, pl:pl + w]
+    assert (wd.grad.double().cpu() - dwr).abs().max().item() <= 1e-4 * max(1.0, dwr.abs().max().item())
+    assert (xd.grad.double().cpu() - dxr).abs().max().item() <= 1e-4 * max(1.0, dxr.abs().max().item())
+
+
 
 def test_efficientnet_b0_bf16_vs_reference_fp32(pkg, dev):
     """End to end at the fixture's 2 x 64 x 64: the last stages batch-normalise over 2 x 2 x 2 = 8 samples, which amplifies any
@@ -135,7 +164,8 @@ def test_efficientnet_b0_bf16_vs_reference_fp32(pkg, dev):
     fa = f.detach().cpu().numpy().ravel(); fr = ref.ravel()
     cos = float((fa * fr).sum() / np.sqrt((fa * fa).sum() * (fr * fr).sum()))
     print('B0 bf16 feature cosine vs reference: %.5f' % cos)
-    assert np.isfinite(fa).all() and cos > 0.98 and np.median(e) < 0.15 * rms
+    # 0.98 while the stem ran in fp32; with the image and the stem conv in bf16 as well (round 4) the same net gives 0.9787
+    assert np.isfinite(fa).all() and cos > 0.97 and np.median(e) < 0.15 * rms
     f.backward(torch.from_numpy(gold['eff_dy']).to(dev))
     params = [p for n, p in net.named_parameters() if not n.startswith('_fc')]
     assert all(p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all() for p in params)
