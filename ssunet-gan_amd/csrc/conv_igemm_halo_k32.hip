@@ -34,9 +34,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifdef SSG_K32_PROBE
 // diagnostic build only (tools/k32_probe.py): per workgroup s_memtime at kernel start / loop start / loop end / kernel end (+ s_memrealtime,
 // 100 MHz, at the first and last: the in-kernel clock)
+// 24 slots per workgroup: 0-3 the four stamps, 4-5 s_memrealtime, 8 + 2 * wave + {0, 1}: cycles wave `wave` spent, summed over the K-steps,
+// (0) on its own vmcnt / lgkmcnt waits at the top of a step and (1) inside the step's s_barrier (waiting for the slowest wave)
+constexpr int SSG_PROBE_SLOTS = 24;
 __device__ unsigned long long* ssg_probe_buf_k32 = nullptr;
-#define SSG_STAMP(i) do { if (ssg_probe_buf_k32 && tid == 0) { ssg_probe_buf_k32[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); \
-                                                            if ((i) == 0 || (i) == 3) ssg_probe_buf_k32[8 * blockIdx.x + 4 + ((i) == 3)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define SSG_STAMP(i) do { if (ssg_probe_buf_k32 && tid == 0) { ssg_probe_buf_k32[SSG_PROBE_SLOTS * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); \
+                                                            if ((i) == 0 || (i) == 3) ssg_probe_buf_k32[SSG_PROBE_SLOTS * blockIdx.x + 4 + ((i) == 3)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define SSG_PROBE_NOW(v) unsigned long long v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) :: "memory")
 #else
 #define SSG_STAMP(i) do { } while (0)
 #endif
@@ -200,15 +204,50 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   write_px();
   SSG_STAMP(1);
 
+#ifdef SSG_K32_PROBE
+  unsigned long long probe_own = 0, probe_bar = 0;
+#endif
   for (int chunk = 0; chunk < nchunks; ++chunk) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int s = chunk * 9 + t;
+#ifndef SSG_K32_MIDBAR
+#define SSG_K32_MIDBAR 0                                   // 1: the step's barrier sits in the MIDDLE of its MFMA stream (below); 0: at the top.  Measured equal (same-box A/B, +-0.5 % on five shapes): kept as a build switch
+#endif
+#if SSG_K32_MIDBAR
+      // The barrier that makes a weight stage visible does not have to sit where the stage is first read.  The per-wave stamps of the
+      // top-of-step form (tools/k32_probe.py) show the two waves of a SIMD running one AFTER the other (waves 0-3 finish their 96
+      // MFMAs and sit ~1 500 cycles in the barrier while waves 4-7 run theirs), so behind a top-of-step barrier every wave reads its
+      // fragments at once and the matrix pipe idles until the first of them land.  Here the barrier for stage s + 1 is arrived at after
+      // the first half of step s's MFMAs: a wave that comes out of it still has half a step of MFMAs queued, and the fast wave of a
+      // SIMD reads its next fragments while the slow one multiplies.  Stage s itself was made visible by the barrier in the middle of
+      // step s - 1; the slot the pieces of step s + 2 overwrite (stage s - 1) was last read at the top of step s - 1, before that
+      // barrier, by every wave.  Only the top of a chunk keeps a barrier of its own: the rewritten pixel image (and, for chunk 0, the
+      // first stage) must be visible before tap 0 reads it -- every wave has passed the middle of tap 8, i.e. its last reads of the
+      // old image, when the first wave writes.
+      if (t == 0) {
+        if (chunk > 0) write_px();
+        wait_vmcnt<B_PC>();
+        wait_lds_reads();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+#else
+#ifdef SSG_K32_PROBE
+      SSG_PROBE_NOW(pb0);
+#endif
       if (t == LD_T + 1 || t == LD_T + 2) wait_vmcnt<B_PC + NLD>();      // the pixel loads issued at LD_T may still be in flight
       else wait_vmcnt<B_PC>();
       wait_lds_reads();
+#ifdef SSG_K32_PROBE
+      SSG_PROBE_NOW(pb1);
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef SSG_K32_PROBE
+      SSG_PROBE_NOW(pb2);
+      probe_own += pb1 - pb0; probe_bar += pb2 - pb1;
+#endif
       if (t == 0 && chunk > 0) {
         // every wave has left the last tap of the previous chunk: replace the image
         write_px();
@@ -216,6 +255,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
+#endif
 #ifndef SSG_K32_DMA_MID
 #define SSG_K32_DMA_MID 1                                  // 1: the step's DMA / pixel loads are issued in the middle of its MFMA stream (A/B build switch)
 #endif
@@ -253,6 +293,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
         for (int q = 0; q < 3; ++q) w[j][q] = *(const bf16x8*)(st + (j * 3 + q) * 1024);
 #endif
+#ifndef SSG_K32_DYNPRIO
+#define SSG_K32_DYNPRIO 1                                  // 1: a wave's priority falls as it advances through a step (A/B build switch: +1 % on the <8,128> shapes, the older wave's barrier wait 1 500 -> 700 cycles per step)
+#endif
+      // The stamps show the older wave of each SIMD pair finishing its 96 MFMAs ~1 500 cycles before the younger one, which then
+      // multiplies alone -- and a lone wave issues a 16-pass MFMA only every other slot.  Priority by progress instead of by age: a wave
+      // early in its step outranks one that is late in it, so the pair stays together.
+      if (SSG_K32_DYNPRIO) __builtin_amdgcn_s_setprio(3);
       // small terms first
 #define SSG_K32_TERM(QW, QP)                                                                      \
   _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                  \
@@ -268,8 +315,32 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
         if (t == LD_T) load_px(chunk + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (SSG_K32_DYNPRIO) __builtin_amdgcn_s_setprio(2);
       SSG_K32_TERM(0, 2)
+#if SSG_K32_MIDBAR
+      {
+        // stage s + 1 (issued during step s - 1) has landed in this wave; in flight behind it: this step's pieces and, around LD_T, the
+        // pixel loads (issued after the pieces of step LD_T, before those of LD_T + 1)
+#ifdef SSG_K32_PROBE
+        SSG_PROBE_NOW(pb0);
+#endif
+        if (t == LD_T || t == LD_T + 1) wait_vmcnt<B_PC + NLD>();
+        else wait_vmcnt<B_PC>();
+        wait_lds_reads();
+#ifdef SSG_K32_PROBE
+        SSG_PROBE_NOW(pb1);
+#endif
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifdef SSG_K32_PROBE
+        SSG_PROBE_NOW(pb2);
+        probe_own += pb1 - pb0; probe_bar += pb2 - pb1;
+#endif
+      }
+#endif
+      if (SSG_K32_DYNPRIO) __builtin_amdgcn_s_setprio(1);
       SSG_K32_TERM(1, 0) SSG_K32_TERM(0, 1)
+      if (SSG_K32_DYNPRIO) __builtin_amdgcn_s_setprio(0);
       SSG_K32_TERM(0, 0)
 #undef SSG_K32_TERM
       if (t == 8) {                                      // the loads of LD_T landed before tap 7's barrier
@@ -286,6 +357,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   wait_vmcnt<0>();
   wait_lds_reads();
   SSG_STAMP(2);
+#ifdef SSG_K32_PROBE
+  if (ssg_probe_buf_k32 && lane == 0) {
+    ssg_probe_buf_k32[SSG_PROBE_SLOTS * blockIdx.x + 8 + 2 * wave] = probe_own;
+    ssg_probe_buf_k32[SSG_PROBE_SLOTS * blockIdx.x + 9 + 2 * wave] = probe_bar;
+  }
+#endif
 
   // ---- non-finite operands (conv_slow.h): a workgroup that holds a non-finite accumulator recomputes its tile with fp32 FMAs
   {

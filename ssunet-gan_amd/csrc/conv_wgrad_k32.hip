@@ -210,6 +210,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
         for (int q = 0; q < 3; ++q) df[j][q] = frag(db + q * DPLANE, doff[j][0], doff[j][1]);
 #pragma unroll
       for (int dyi = 0; dyi < 3; ++dyi) {
+#ifndef SSG_WK32_DYNPRIO
+#define SSG_WK32_DYNPRIO 1                                 // 1: a wave's priority falls as it advances through a step (as conv_halo_k32_kernel; A/B build switch)
+#endif
+        if (SSG_WK32_DYNPRIO) { if (dyi == 0) __builtin_amdgcn_s_setprio(3); else if (dyi == 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
         const unsigned char* xb = ximg + ((gy + dyi) & 3) * XSLOT;        // row gy - 1 + dyi -> slot (row + 1) & 3
         bf16x8 xf[3][3];
 #pragma unroll
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
         }
 #endif
       }
+      if (SSG_WK32_DYNPRIO) __builtin_amdgcn_s_setprio(0);
       if (more) {
         __builtin_amdgcn_sched_barrier(0);
         store_x(nx, (gy + 3) & 3, XF ? x_inside(gy + 2, gx0) : true);      // row gy + 2

@@ -14,7 +14,8 @@ from ssunet_gan_amd import ops, _lib
 from ssunet_gan_amd._lib import ACT_NONE
 dev = 'cuda'
 lib = _lib.load()
-probe = torch.zeros(8 * 65536, dtype=torch.int64, device=dev)
+SLOTS = 24
+probe = torch.zeros(SLOTS * 65536, dtype=torch.int64, device=dev)
 assert lib.ssg_debug_set_probe_buffer_k32(C.c_void_p(probe.data_ptr())) == 0
 ops.MFMA_SPLIT = True
 torch.manual_seed(0)
@@ -29,9 +30,15 @@ for (ci, co, hw) in [(64, 64, 512), (192, 64, 512), (128, 128, 256), (512, 512, 
     probe.zero_()
     y = ops._conv_fwd_impl(x, None, w, None, 1, 1, ACT_NONE, 0.0)
     torch.cuda.synchronize()
-    p = probe.cpu().view(-1, 8)
+    p = probe.cpu().view(-1, SLOTS)
     p = p[p[:, 3] > 0].double()
     d = lambda a, b: (p[:, b] - p[:, a]).median().item()
     clk = ((p[:, 3] - p[:, 0]) / (p[:, 5] - p[:, 4]).clamp(min=1) * 100e6).median().item() / 1e9
     print('cin%d cout%d %dx%d: %d workgroups; per tile (median cycles): prologue %.0f, main loop %.0f (%.0f per step; MFMA issue alone: 3072), epilogue + store drain %.0f, '
           'total %.0f; in-kernel clock %.2f GHz (s_memtime / s_memrealtime)' % (ci, co, hw, hw, p.shape[0], d(0, 1), d(1, 2), d(1, 2) / (ci // 32 * 9), d(2, 3), d(0, 3), clk), flush=True)
+    nst = ci // 32 * 9
+    nw = 8 if (p[:, 8 + 2 * 7] + p[:, 9 + 2 * 7]).median().item() > 0 else 4
+    own = [p[:, 8 + 2 * w].median().item() / nst for w in range(nw)]
+    bar = [p[:, 9 + 2 * w].median().item() / nst for w in range(nw)]
+    print('    per K-step and wave (median over workgroups), cycles on its own vmcnt / LDS waits at the top of the step: ' + ' '.join('%.0f' % v for v in own), flush=True)
+    print('    ... and inside the s_barrier (waiting for the slowest wave):                                             ' + ' '.join('%.0f' % v for v in bar), flush=True)
