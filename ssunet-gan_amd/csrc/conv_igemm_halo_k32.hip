@@ -56,16 +56,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   constexpr int TW = 32, BM = TH * TW;
   constexpr int HW = TW + 2, HR = (TH + 2) * HW;
   constexpr int NPIX = (HR + 15) / 16 * 16;
-  constexpr int PLANE = 4 * NPIX * 16;                   // bytes of one plane of the pixel image
-  constexpr int IMG = 3 * PLANE;
+  constexpr int KGS = NPIX * 16 + 64;                    // bytes between the k-groups of a plane: + 64 B so that the 8-byte writes of the four k-groups of a pixel land on distinct banks (reads go 16 lanes = one k-group at a time and do not care)
+  constexpr int PLANE = 4 * KGS;                         // bytes of one plane of the pixel image
+  constexpr int IMG = (3 * PLANE + 1023) / 1024 * 1024;
   constexpr int BSTG = BN * 192;                         // bytes of one weight stage (one tap x 32 channels x 3 planes)
   constexpr int BPIECES = BSTG / 1024;
   constexpr int B_PC = (BPIECES + NW - 1) / NW;          // per wave and step; piece indices >= BPIECES are dummies (<16, 64>: 12 pieces, 8 waves)
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / 16, NI = WTN / 16;
-  constexpr int NBLK = (HR + 63) / 64, ITEMS = NBLK * 4, IPW = ITEMS / NW, NLD = 2 * IPW;
+  // Pixel loads: one instruction = 8 consecutive halo pixels x the chunk's 128 bytes (lane = pixel p8, 16-byte quarter q): eight
+  // whole lines.  (The first form -- lane = pixel, 32 bytes of one k-group each -- touched 64 lines per instruction, every line from
+  // eight instructions of different waves: with the same bytes in lane order the K-step of the 16 x 32 x 64 tile ran 10-14 % faster
+  // and that of the 8 x 32 x 128 tile 3-4 %, tools/k32_probe.py.)
+  constexpr int NGRP = (HR + 7) / 8, GPW = (NGRP + NW - 1) / NW, NLD = GPW;
   constexpr int LD_T = 4;                                // tap step at which the next chunk's pixel loads are issued
-  static_assert(ITEMS % NW == 0, "uniform load items per wave");
   static_assert(IMG % 1024 == 0, "the ring behind the image stays 1-KiB aligned");
   static_assert(WTM == 64, "a wave owns two 32-pixel tile rows");
 
@@ -101,23 +105,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   const auto w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)((unsigned)nyt * (unsigned)nsteps * (unsigned)BSTG), 0x00020000);
   const unsigned w_tile = (unsigned)nt * (unsigned)nsteps * (unsigned)BSTG;
 
-  // ---- pixel load items of this thread: item (wave * IPW + k) = (64-pixel block of the halo, k-group); lane = pixel of the block
-  unsigned px_pix[IPW];                                  // pixel index in the input tensor, or OOB
-  int px_dst[IPW];                                       // byte offset in a plane of the image, or -1 (lane beyond the halo)
-  unsigned px_kg[IPW];
-#pragma unroll
-  for (int k = 0; k < IPW; ++k) {
-    const int it = wave * IPW + k;
-    const int blk = it >> 2, g = it & 3;
-    const int hp = blk * 64 + lane;
+  // ---- pixel load items of this thread: group (wave * GPW + k) of 8 halo pixels; lane = (pixel p8 of the group, quarter q of the chunk)
+  const int p8 = lane >> 3, q8 = lane & 7;
+  const int hp0 = wave * GPW * 8 + p8;                   // halo pixel of item 0; item k: + 8 k
+  // pixel index of item k in the input tensor, or OOB -- recomputed where it is used (a dozen vector instructions per load, ten loads per
+  // 9 K-steps) rather than kept: the hot loop has no registers for a table
+  const int pix_base = (n * a.H + ty * TH - 1) * a.W + tx * TW - 1;
+  auto px_pix_of = [&](int k) -> unsigned {
+    const int hp = hp0 + 8 * k;
     const int hy = hp / HW, hx = hp - hy * HW;
-    const int iy = ty * TH + hy - 1, ix = tx * TW + hx - 1;
-    const bool in_halo = hp < HR;
-    const bool ok = in_halo && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    px_pix[k] = ok ? (unsigned)((n * a.H + iy) * a.W + ix) : OOB;
-    px_dst[k] = in_halo ? (g * NPIX + hp) * 16 : -1;
-    px_kg[k] = (unsigned)g * 32u;
-  }
+    const bool ok = hp < HR && (unsigned)(ty * TH + hy - 1) < (unsigned)a.H && (unsigned)(tx * TW + hx - 1) < (unsigned)a.W;
+    return ok ? (unsigned)(pix_base + hy * a.W + hx) : OOB;
+  };
+  const int px_dst0 = (q8 >> 1) * KGS + hp0 * 16 + (q8 & 1) * 8;      // byte offset of item 0 in a plane of the image; item k: + 128 k
   u32x4 raw[NLD];
   auto load_px = [&](int chunk) {
     const int c0 = chunk * 32;
@@ -126,41 +126,34 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     const unsigned ld4 = (unsigned)(first ? a.ld1 : a.ld2) * 4u;
     const unsigned so = (unsigned)(first ? c0 : c0 - a.C1) * 4u;
 #pragma unroll
-    for (int k = 0; k < IPW; ++k) {
-      const unsigned vo = (live && px_pix[k] != OOB) ? px_pix[k] * ld4 + px_kg[k] : OOB;
-      const unsigned vo2 = (live && px_pix[k] != OOB) ? vo + 16u : OOB;
-      if (first) {
-        raw[2 * k] = __builtin_amdgcn_raw_buffer_load_b128(in1_rs, vo, so, 0);
-        raw[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(in1_rs, vo2, so, 0);
-      } else {
-        raw[2 * k] = __builtin_amdgcn_raw_buffer_load_b128(in2_rs, vo, so, 0);
-        raw[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b128(in2_rs, vo2, so, 0);
-      }
+    for (int k = 0; k < GPW; ++k) {
+      const unsigned pix = px_pix_of(k);
+      const unsigned vo = (live && pix != OOB) ? pix * ld4 + (unsigned)q8 * 16u : OOB;
+      if (first) raw[k] = __builtin_amdgcn_raw_buffer_load_b128(in1_rs, vo, so, 0);
+      else raw[k] = __builtin_amdgcn_raw_buffer_load_b128(in2_rs, vo, so, 0);
     }
   };
-  bf16x8 cv[IPW][3];
+  bf16x4 cv[GPW][3];
   auto convert_px = [&](int chunk) {                     // chunk: the one whose loads sit in raw[]
 #pragma unroll
-    for (int k = 0; k < IPW; ++k) {
-      f32x4 lo = __builtin_bit_cast(f32x4, raw[2 * k]), hi = __builtin_bit_cast(f32x4, raw[2 * k + 1]);
+    for (int k = 0; k < GPW; ++k) {
+      f32x4 v = __builtin_bit_cast(f32x4, raw[k]);
       if constexpr (XF) {
-        const int cb = (chunk < nchunks ? chunk : nchunks - 1) * 32 + (int)(px_kg[k] >> 2);      // this item's 8 channels (C2 == 0)
-        const f32x4 s0 = *(const f32x4*)(xtab + cb), s1 = *(const f32x4*)(xtab + cb + 4);
-        const f32x4 h0 = *(const f32x4*)(xtab + a.C1 + cb), h1 = *(const f32x4*)(xtab + a.C1 + cb + 4);
-        lo = lo * s0 + h0; hi = hi * s1 + h1;            // bn_apply_kernel's expression
+        const int cb = (chunk < nchunks ? chunk : nchunks - 1) * 32 + q8 * 4;       // this lane's 4 channels (C2 == 0)
+        v = v * *(const f32x4*)(xtab + cb) + *(const f32x4*)(xtab + a.C1 + cb);     // bn_apply_kernel's expression
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { lo[e] = ssg_act(lo[e], a.in_act, a.in_slope); hi[e] = ssg_act(hi[e], a.in_act, a.in_slope); }
-        if (px_pix[k] == OOB) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = lo; }
+        for (int e = 0; e < 4; ++e) v[e] = ssg_act(v[e], a.in_act, a.in_slope);
+        if (px_pix_of(k) == OOB) v = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      split3(lo, hi, cv[k][0], cv[k][1], cv[k][2]);
+      split3_4(v, cv[k][0], cv[k][1], cv[k][2]);
     }
   };
   auto write_px = [&]() {
 #pragma unroll
-    for (int k = 0; k < IPW; ++k) {
-      if (px_dst[k] >= 0) {
+    for (int k = 0; k < GPW; ++k) {
+      if (hp0 + 8 * k < HR) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *(bf16x8*)(img + q * PLANE + px_dst[k]) = cv[k][q];
+        for (int pl = 0; pl < 3; ++pl) *(bf16x4*)(img + pl * PLANE + px_dst0 + 128 * k) = cv[k][pl];
       }
     }
   };
@@ -186,7 +179,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int p = wm * WTM + i * 16 + l15;
-    pb[i] = (kg * NPIX + ((p >> 5) + 1) * HW + (p & 31) + 1) * 16;
+    pb[i] = kg * KGS + (((p >> 5) + 1) * HW + (p & 31) + 1) * 16;
   }
   const int wfrag = wn * NI * 3 * 1024 + lane * 16;      // this lane's 16 bytes of fragment (wn * NI + j), plane q: + (j * 3 + q) * 1024
 
@@ -508,7 +501,7 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   a.xcd_swizzle = swz;
   a.ntiles_n = (a.Cout + BN - 1) / BN;                    // narrow tiles (BN 16 / 32): the last columns may be padding
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ntiles_n));
-  constexpr int lds_bytes = 3 * 4 * NPIX * 16 + 3 * BN * 192 + 1024;
+  constexpr int lds_bytes = (3 * 4 * (NPIX * 16 + 64) + 1023) / 1024 * 1024 + 3 * BN * 192 + 1024;
   static_assert(lds_bytes <= 160 * 1024 && (NW != 4 || BN <= 32 || lds_bytes <= 80 * 1024), "LDS budget");
   constexpr int tab_bytes = XF ? 2 * SSG_K32_XF_MAXC * 4 : 0;       // scale | shift of up to SSG_K32_XF_MAXC input channels
   static_assert(lds_bytes + tab_bytes <= 160 * 1024, "LDS budget with the input-transform table");
@@ -566,7 +559,7 @@ int ssg_conv_halo_k32_fmt(const ConvArgs& a) {
   if (a.Cout % 64 == 0) {
     static const int t16 = [] { const char* e = getenv("SSG_K32_T16"); return e ? atoi(e) : 1; }();
     const long long wgs16 = (long long)a.N * ((a.GH + 15) / 16) * ((a.GW + 31) / 32) * (a.Cout / 64);
-    if (t16 && a.GH >= 16 && (wgs16 >= 2048 || (on == 2 && a.GH % 16 == 0))) return 2064;   // 16 x 32-pixel x 64-channel tiles, 512 threads (same pack as 1064)
+    if (t16 && !a.in_scale && a.GH >= 16 && (wgs16 >= 2048 || (on == 2 && a.GH % 16 == 0))) return 2064;   // (with the fused input transform the 16-row tile spills: those launches take <4,64>)   // 16 x 32-pixel x 64-channel tiles, 512 threads (same pack as 1064)
     const long long wgs = (long long)a.N * ((a.GH + 3) / 4) * ((a.GW + 31) / 32) * (a.Cout / 64);
     if (on == 2 || wgs >= 1536) return 1064;
   }
@@ -575,9 +568,9 @@ int ssg_conv_halo_k32_fmt(const ConvArgs& a) {
 
 void ssg_conv_halo_k32_tile(int fmt, int* th, int* tw) { *tw = 32; *th = (fmt == 1128 || fmt == 1016 || fmt == 1032) ? 8 : (fmt == 2064 ? 16 : 4); }
 
-// fused input transform (ssg_conv_desc.in_scale): the three wide tiles, one input pointer, a table that fits beside the image
+// fused input transform (ssg_conv_desc.in_scale): the <8,128> and <4,64> tiles, one input pointer, a table that fits beside the image
 bool ssg_conv_halo_k32_in_affine_ok(const ConvArgs& a, int fmt) {
-  if (fmt != 1128 && fmt != 1064 && fmt != 2064) return false;
+  if (fmt != 1128 && fmt != 1064) return false;
   if (a.C2 != 0 || a.C1 > SSG_K32_XF_MAXC) return false;
   return a.in_act == SSG_ACT_NONE || a.in_act == SSG_ACT_RELU || a.in_act == SSG_ACT_LRELU;
 }
@@ -586,8 +579,7 @@ int ssg_conv_igemm_halo_k32_launch(const ConvArgs& a, int fmt, hipStream_t st) {
   if (a.in_scale) {
     if (!a.in_shift || !ssg_conv_halo_k32_in_affine_ok(a, fmt)) { ssg_set_error("conv halo k32: in_scale on a launch without the fused input transform"); return SSG_EINVAL; }
     if (fmt == 1128) return launch<8, 128, 4, 2, true>(a, st);
-    if (fmt == 1064) return launch<4, 64, 2, 2, true>(a, st);
-    return launch<16, 64, 8, 1, true>(a, st);
+    return launch<4, 64, 2, 2, true>(a, st);
   }
   if (fmt == 1128) return launch<8, 128, 4, 2>(a, st);
   if (fmt == 1064) return launch<4, 64, 2, 2>(a, st);

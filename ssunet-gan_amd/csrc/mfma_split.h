@@ -4,6 +4,7 @@
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XROW = 96;                  // bytes per weight row per K-step: 3 planes x 16 bf16, dense
 // 16-B slot (plane p, k-half h) of row r sits at position (2p + h) ^ ((r >> 3) & 1): with the 96-B pitch the slot index of a row
@@ -15,6 +16,19 @@ __device__ __forceinline__ void split3(const f32x4& u, const f32x4& v, bf16x8& p
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float x = e < 4 ? u[e] : v[e - 4];
+    const __bf16 h = (__bf16)x;
+    const float r = x - (float)h;
+    const __bf16 m = (__bf16)r;
+    const float r2 = r - (float)m;
+    p1[e] = h; p2[e] = m; p3[e] = (__bf16)r2;
+  }
+}
+
+// the same split for one quad of values
+__device__ __forceinline__ void split3_4(const f32x4& u, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = u[e];
     const __bf16 h = (__bf16)x;
     const float r = x - (float)h;
     const __bf16 m = (__bf16)r;

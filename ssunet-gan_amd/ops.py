@@ -310,6 +310,7 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
         d.in_scale = in_affine[0].data_ptr(); d.in_shift = in_affine[1].data_ptr(); d.in_act = int(in_affine[2]); d.in_slope = float(in_affine[3])
         if split is None or not call('ssg_conv2d_in_affine_ok', C.byref(d)):
             return _DECLINED
+        bn = call('ssg_conv2d_split_bn', C.byref(d))      # with the transform a 16-row launch becomes a 4-row one (same pack)
     part = None
     if want_bn and BN_EPILOGUE:
         rows = call('ssg_conv2d_bnpart_rows', C.byref(d))

@@ -36,6 +36,7 @@ for (ci, co, hw) in [(64, 64, 512), (192, 64, 512), (128, 128, 256), (512, 512, 
     clk = ((p[:, 3] - p[:, 0]) / (p[:, 5] - p[:, 4]).clamp(min=1) * 100e6).median().item() / 1e9
     print('cin%d cout%d %dx%d: %d workgroups; per tile (median cycles): prologue %.0f, main loop %.0f (%.0f per step; MFMA issue alone: 3072), epilogue + store drain %.0f, '
           'total %.0f; in-kernel clock %.2f GHz (s_memtime / s_memrealtime)' % (ci, co, hw, hw, p.shape[0], d(0, 1), d(1, 2), d(1, 2) / (ci // 32 * 9), d(2, 3), d(0, 3), clk), flush=True)
+    print('    prologue split: entry -> loads issued %.0f, -> pixels landed %.0f, -> split + written %.0f' % (d(7, 0), d(0, 6), d(6, 1)), flush=True)
     nst = ci // 32 * 9
     nw = 8 if (p[:, 8 + 2 * 7] + p[:, 9 + 2 * 7]).median().item() > 0 else 4
     own = [p[:, 8 + 2 * w].median().item() / nst for w in range(nw)]
