@@ -102,6 +102,16 @@ __device__ __forceinline__ float ssg_swish_grad(float z) {
 // ~total / (256 * items) blocks.  The grid-stride loop over 4096 blocks that these kernels used through round 3 strides 16 MB per
 // iteration (a 1-GiB copy: 4.5-4.8 TB/s); contiguous chunks read 5.4-5.9, one item per thread 6.3 (tools/mfma_lab.hip, `copy`).
 __device__ __forceinline__ long long ssg_chunk_len(long long total) { return (((total + gridDim.x - 1) / gridDim.x) + 255) / 256 * 256; }
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), the result in every lane of the row: four data-parallel-primitive moves on
+// the vector unit (quad swaps, half-row mirror, row mirror).  __shfl_xor compiles to ds_bpermute_b32 -- an LDS-crossbar operation per step:
+// the 128 of them in the statistics epilogue of conv_halo_k32_kernel were 7-10 % of a Cin = 64 tile.
+__device__ __forceinline__ float ssg_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
+  return v;
+}
 // Workgroup ids are dealt to the 8 XCDs round-robin; map id -> position so that XCD k owns the k-th contiguous band of [0, n) and
 // walks it in dispatch order (neighbouring positions then share one L2).
 __device__ __forceinline__ unsigned ssg_xcd_band(unsigned id, unsigned n) {

@@ -404,8 +404,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
 #pragma unroll
   for (int i = 0; i < MI; ++i) nvl += pok[i] ? 1.f : 0.f;
   if (want_bn) {
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) nvl += __shfl_xor(nvl, m, 64);       // valid pixels of this wave's 16-lane row group
+    nvl = ssg_row16_sum(nvl);                              // valid pixels of this wave's 16-lane row group
   }
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -419,15 +418,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
       // S1 = s1 + n*c, S2 = s2 + 2*c*s1 + n*c^2 (plain fp32 sums of v and v^2 lose var = E[v^2] - mean^2 once |mean| >> std).
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float piv = __shfl(acc[0][j][r] + bv[r], lane & 48, 64);
+        const float piv = ssg_row16_sum(acc[0][j][r] + bv[r]) * 0.0625f;   // any value the 16 lanes share will do: the mean of their first pixels (bitwise the same in every lane: each step adds a lane and its partner)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           const float dv = pok[i] ? (acc[i][j][r] + bv[r]) - piv : 0.f;
           s1 += dv; s2 += dv * dv;
         }
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+        s1 = ssg_row16_sum(s1); s2 = ssg_row16_sum(s2);
         if (l15 == 0) {
           const double c = (double)piv, nn = (double)nvl;
           const int col = wn * WTN + j * 16 + kg * 4 + r;
