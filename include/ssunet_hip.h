@@ -90,6 +90,13 @@ typedef struct {
    * materialised; zero padding applies to the ACTIVATED tensor.  in_scale = NULL: off.  Only where ssg_conv2d_in_affine_ok(d)
    * returns 1 (split-operand k32 kernels, one input pointer, C1 <= 512, in_act none / ReLU / leaky ReLU). */
   const float* in_scale; const float* in_shift; int in_act; float in_slope;
+  /* ABI 9: batch-norm BACKWARD statistics in the epilogue of the input-gradient launch that produces the gradient of an activation
+   * y = act(x * scale[c] + shift[c]) (archs.py:229-230: the dgrad of conv2 produces d(relu(bn1(c1)))): the launch multiplies its result by
+   * act'(.) recomputed from bwd_x (= c1, same shape and pixel order as `out`, pixel stride bwd_ldx) with bwd_scale / bwd_shift, WRITES THE
+   * MASKED GRADIENT g, and fills `bnpart` (which must be set) with per-tile rows (sum g, sum g * (x - bwd_mean[c])) instead of the forward's
+   * (sum, sum of squares): what ssg_bn_bwd_reduce_f32 would have read g and x again for.  bwd_x = NULL: off.  Only where
+   * ssg_conv2d_bwd_stats_ok(d) returns 1 (the wide split-operand k32 tiles; no res, act, in_scale). */
+  const float* bwd_x; int bwd_ldx; const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; int bwd_act; float bwd_slope;
 } ssg_conv_desc;
 
 /* fp32 convolution on the bf16 matrix pipe (3x3, unit stride; archs.py:210,212 and their input gradients, models_seg_gan.py:37-39
@@ -107,6 +114,7 @@ typedef struct {
  * where the grid fills the chip (default, SSG_K32) / wherever the shape is legal (tests). */
 int ssg_conv2d_split_bn(const ssg_conv_desc* d);
 int ssg_conv2d_in_affine_ok(const ssg_conv_desc* d);   /* ABI 8: 1 when the launch for `d` (w_split set) takes in_scale / in_shift */
+int ssg_conv2d_bwd_stats_ok(const ssg_conv_desc* d);   /* ABI 9: 1 when the launch for `d` (w_split set) takes bwd_x ... */
 int ssg_conv_set_k32_mode(int mode);
 int64_t ssg_pack_weights_split_bytes(int R, int Kp, int BN);
 int ssg_pack_weights_split_bf16x3(const float* w_packed, int R, int Kp, int BN, void* out, void* stream);

@@ -37,6 +37,8 @@ class ConvDesc(C.Structure):
         ('ws', C.c_void_p), ('ws_bytes', C.c_int64),
         ('w_split', C.c_void_p), ('parity_merge', C.c_int),
         ('in_scale', C.c_void_p), ('in_shift', C.c_void_p), ('in_act', C.c_int), ('in_slope', C.c_float),
+        ('bwd_x', C.c_void_p), ('bwd_ldx', C.c_int), ('bwd_scale', C.c_void_p), ('bwd_shift', C.c_void_p), ('bwd_mean', C.c_void_p),
+        ('bwd_act', C.c_int), ('bwd_slope', C.c_float),
     ]
 
 
@@ -82,6 +84,7 @@ SIGNATURES = {
     'ssg_conv2d_thin_bf16_dgrad': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'ssg_conv2d_split_bn': [C.POINTER(ConvDesc)],
     'ssg_conv2d_in_affine_ok': [C.POINTER(ConvDesc)],
+    'ssg_conv2d_bwd_stats_ok': [C.POINTER(ConvDesc)],
     'ssg_conv2d_wgrad_in_affine_ok': [C.POINTER(WgradDesc)],
     'ssg_pack_weights_split_bytes': [_I, _I, _I],
     'ssg_conv_set_k32_mode': [_I],
@@ -191,10 +194,10 @@ _RESTYPES = {
     'ssg_conv2d_thin_bf16_wgrad_workspace_bytes': C.c_int64,
     'ssg_bn_stats_from_partials_workspace_bytes': C.c_int64,
 }
-_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_split_bn', 'ssg_conv2d_in_affine_ok', 'ssg_conv2d_wgrad_in_affine_ok', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
+_NO_STATUS = set(_RESTYPES) | {'ssg_abi_version', 'ssg_conv2d_split_bn', 'ssg_conv2d_in_affine_ok', 'ssg_conv2d_wgrad_in_affine_ok', 'ssg_conv2d_bwd_stats_ok', 'ssg_conv2d_kernel_id', 'ssg_conv2d_bnpart_rows', 'ssg_conv2d_wgrad_kernel_id',
                                 'ssg_spade_conv_modulate_ok', 'ssg_se_gate_ok'}
 
-ABI_VERSION = 8          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
+ABI_VERSION = 9          # ssg_abi_version() of the library this ctypes table (ConvDesc layout, SIGNATURES) was written against
 
 _lib = None
 

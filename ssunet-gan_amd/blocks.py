@@ -73,8 +73,15 @@ class _BasicBlockFn(torch.autograd.Function):
                 del y1w
         else:
             dw2 = _conv_wgrad_impl(y1, None, dc2, w2.shape, 1, 1)
-        dy1 = _conv_dgrad_impl(dc2, w2, 1, 1, c1.shape[2], c1.shape[3], 0, c1.shape[1])
-        dc1, _, dg1, db1 = _bn_bwd_impl(c1, y1, dy1, g1, st1, ACT_RELU, 0.0, group, cnt1, want_dres=False, had_res=False)
+        # bn1's backward sums ride the epilogue of the input gradient that produces d(relu(bn1(c1))) where its kernel has one
+        # (ssg_conv_desc.bwd_x: the k32 tiles): the reduce pass over (dy1, c1) goes, the apply pass reads the already masked gradient
+        r = _conv_dgrad_impl(dc2, w2, 1, 1, c1.shape[2], c1.shape[3], 0, c1.shape[1], bwd_stats=(c1, st1, ACT_RELU, 0.0)) \
+            if ops.BN_BWD_EPILOGUE else None
+        if r is not None:
+            dc1, dg1, db1 = ops._bn_bwd_from_partials(c1, r[0], r[1], g1, st1, group, cnt1)
+        else:
+            dy1 = _conv_dgrad_impl(dc2, w2, 1, 1, c1.shape[2], c1.shape[3], 0, c1.shape[1])
+            dc1, _, dg1, db1 = _bn_bwd_impl(c1, y1, dy1, g1, st1, ACT_RELU, 0.0, group, cnt1, want_dres=False, had_res=False)
         dw1 = _conv_wgrad_impl(x1, x2, dc1, w1.shape, stride, 1)
         dwsc = _conv_wgrad_impl(x1, x2, g, wsc.shape, stride, 0) if wsc is not None else None
         dx1 = dx2 = None

@@ -20,6 +20,7 @@ struct ConvArgs {
   float* ws; int ksplit;         // conv_igemm_halo.hip: split-K slabs [ksplit][N*GH*GW][pad4(Cout)] (ksplit <= 1: off)
   int parity;                    // ssg_conv_desc.parity_merge
   const float* in_scale; const float* in_shift; int in_act; float in_slope;   // ssg_conv_desc.in_scale (conv_igemm_halo_k32.hip, conv_slow.h)
+  const float* bwd_x; int bwd_ldx; const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; int bwd_act; float bwd_slope;   // ssg_conv_desc.bwd_x (conv_igemm_halo_k32.hip)
   const float* w32;              // split-operand launches: the fp32 packed weights (ssg_conv_desc.w) beside the split pack in `w` (conv_slow.h)
 };
 
@@ -45,6 +46,7 @@ int ssg_conv_igemm_halo_x3_parity_launch(const ConvArgs& a, hipStream_t st);
 int ssg_conv_halo_k32_fmt(const ConvArgs& a);
 void ssg_conv_halo_k32_tile(int fmt, int* th, int* tw);
 bool ssg_conv_halo_k32_in_affine_ok(const ConvArgs& a, int fmt);
+bool ssg_conv_halo_k32_bwd_stats_ok(const ConvArgs& a, int fmt);
 int ssg_conv_igemm_halo_k32_launch(const ConvArgs& a, int fmt, hipStream_t st);
 int ssg_pack_split_k32_launch(const float* w_packed, int R, int Kp, int BN, void* out, hipStream_t st);
 // conv_igemm_dma_x3.hip: the LDS-DMA pipeline (1x1, stride 2, parity classes) with split operands; column tile 128 / 64 or 0 = not eligible

@@ -294,6 +294,8 @@ ConvArgs to_args(const ssg_conv_desc* d) {
   a.parity = d->parity_merge;
   a.w32 = d->w;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_act = d->in_act; a.in_slope = d->in_slope;
+  a.bwd_x = d->bwd_x; a.bwd_ldx = d->bwd_ldx; a.bwd_scale = d->bwd_scale; a.bwd_shift = d->bwd_shift; a.bwd_mean = d->bwd_mean;
+  a.bwd_act = d->bwd_act; a.bwd_slope = d->bwd_slope;
   return a;
 }
 
@@ -352,6 +354,7 @@ static int64_t splitk_bytes(const ssg_conv_desc* d, int* ksplit) {
 }
 
 extern "C" int ssg_conv2d_in_affine_ok(const ssg_conv_desc* d);
+extern "C" int ssg_conv2d_bwd_stats_ok(const ssg_conv_desc* d);
 extern "C" int ssg_conv2d_split_bn(const ssg_conv_desc* d) {
   if (!d || validate(d) != SSG_OK || ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d) || ssg_conv1x1_k64_ok(d)) return 0;
   return split_bn(d);
@@ -365,6 +368,14 @@ extern "C" int ssg_conv2d_in_affine_ok(const ssg_conv_desc* d) {
   return fmt >= 1000 && ssg_conv_halo_k32_in_affine_ok(to_args(d), fmt) ? 1 : 0;
 }
 
+// 1 when the launch for `d` masks its output and writes the batch-norm backward sums (ssg_conv_desc.bwd_x)
+extern "C" int ssg_conv2d_bwd_stats_ok(const ssg_conv_desc* d) {
+  if (!d || validate(d) != SSG_OK || !d->w_split || d->parity_merge || d->Cout <= 32 || d->res || d->bias || d->act != SSG_ACT_NONE || d->in_scale) return 0;
+  if (ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d) || ssg_conv1x1_k64_ok(d)) return 0;
+  const int fmt = split_bn(d);
+  return fmt >= 1000 && ssg_conv_halo_k32_bwd_stats_ok(to_args(d), fmt) ? 1 : 0;
+}
+
 extern "C" int64_t ssg_conv2d_workspace_bytes(const ssg_conv_desc* d) {
   if (!d || validate(d) != SSG_OK || ssg_thin4_conv_kind(d) || ssg_thin_conv_kind(d)) return 0;
   int k;
@@ -376,6 +387,8 @@ extern "C" int ssg_conv2d_igemm_f32(const ssg_conv_desc* d, void* stream) {
   if (rc != SSG_OK) return rc;
   SSG_REQUIRE(!d->in_scale || (d->in_shift && ssg_conv2d_in_affine_ok(d)), SSG_EINVAL,
               "conv: in_scale on a descriptor whose kernel has no fused input transform (ssg_conv2d_in_affine_ok == 0)");
+  SSG_REQUIRE(!d->bwd_x || (d->bnpart && d->bwd_scale && d->bwd_shift && d->bwd_mean && ssg_conv2d_bwd_stats_ok(d)), SSG_EINVAL,
+              "conv: bwd_x on a descriptor whose kernel has no backward-statistics epilogue (ssg_conv2d_bwd_stats_ok == 0), or without bnpart");
   ConvArgs a = to_args(d);
   hipStream_t st = (hipStream_t)stream;
   if (d->ws && !d->bnpart) {                 // split-K only with a workspace of the size ssg_conv2d_workspace_bytes reports
@@ -432,6 +445,8 @@ extern "C" int ssg_conv2d_f32(const ssg_conv_desc* d, void* stream) {
   if (rc != SSG_OK) return rc;
   SSG_REQUIRE(!d->in_scale || (d->in_shift && ssg_conv2d_in_affine_ok(d)), SSG_EINVAL,
               "conv: in_scale on a descriptor whose kernel has no fused input transform (ssg_conv2d_in_affine_ok == 0)");
+  SSG_REQUIRE(!d->bwd_x || (d->bnpart && d->bwd_scale && d->bwd_shift && d->bwd_mean && ssg_conv2d_bwd_stats_ok(d)), SSG_EINVAL,
+              "conv: bwd_x on a descriptor whose kernel has no backward-statistics epilogue (ssg_conv2d_bwd_stats_ok == 0), or without bnpart");
   SSG_REQUIRE(!d->parity_merge || ssg_conv2d_split_bn(d) == 64, SSG_EINVAL,
               "conv: parity_merge on a descriptor that has no merged-parity kernel (ssg_conv2d_split_bn != 64)");
   if (d->parity_merge) return ssg_conv2d_igemm_f32(d, stream);

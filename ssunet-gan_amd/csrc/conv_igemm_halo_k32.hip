@@ -50,7 +50,10 @@ __device__ unsigned long long* ssg_probe_buf_k32 = nullptr;
 // filled once per workgroup; halo pixels outside the image stay zero (the padding of the ACTIVATED tensor).
 constexpr int SSG_K32_XF_MAXC = 512;                     // <16, 64>: 154 KiB of image + ring leave 4 KiB for the table
 
-template <int TH, int BN, int WAVES_M, int WAVES_N, bool XF = false>
+// BWD: the launch is the input gradient that produces d(act(bn(x))) (ssg_conv_desc.bwd_x): the epilogue reads x, masks its result by
+// act'(x * scale + shift), writes the masked gradient g and per-tile rows (sum g, sum g * (x - mean)) -- the two sums of a batch-norm backward,
+// which a separate pass (ssg_bn_bwd_reduce_f32) would have read g and x again for.
+template <int TH, int BN, int WAVES_M, int WAVES_N, bool XF = false, bool BWD = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 1 : 2) void conv_halo_k32_kernel(const ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int TW = 32, BM = TH * TW;
@@ -406,13 +409,52 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   if (want_bn) {
     nvl = ssg_row16_sum(nvl);                              // valid pixels of this wave's 16-lane row group
   }
+  // BWD: every x quad of this lane's outputs is requested before the first is used (the fragment registers of the main loop are dead: 64 free
+  // registers) -- one load latency for the tile's epilogue instead of one per column fragment
+  f32x4 bx[BWD ? MI : 1][BWD ? NI : 1];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        bx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pok[i]) bx[i][j] = *(const f32x4*)(a.bwd_x + opix[i] * a.bwd_ldx + n0 + wn * WTN + j * 16 + kg * 4);
+      }
+  }
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn * WTN + j * 16 + kg * 4;
     const bool cok = BN >= 64 || co < a.Cout;              // narrow tiles: padding columns (Cout % 4 == 0: whole quads)
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (a.bias && cok) bv = *(const f32x4*)(a.bias + co);
-    if (want_bn) {
+    if constexpr (BWD) {
+      // backward statistics: g = v * act'(z), z = x * scale + shift recomputed with bn_apply_kernel's expression (same bits, same sign);
+      // sums of g and g * (x - mean) over the wave's pixels, fp32 inside the 16-lane group, fp64 beyond; acc is overwritten by g
+      const f32x4 ksc = *(const f32x4*)(a.bwd_scale + co), ksh = *(const f32x4*)(a.bwd_shift + co), kmu = *(const f32x4*)(a.bwd_mean + co);
+      f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const f32x4 xv = bx[i][j];
+        const f32x4 z = xv * ksc + ksh;
+        f32x4 g = acc[i][j] + bv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (!(z[r] > 0.f)) g[r] *= (a.bwd_act == SSG_ACT_RELU ? 0.f : (a.bwd_act == SSG_ACT_LRELU ? a.bwd_slope : 1.f));
+          if (!pok[i]) g[r] = 0.f;
+        }
+        acc[i][j] = g - bv;                              // the store below adds bv back
+        s1v += g; s2v += g * (xv - kmu);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = ssg_row16_sum(s1v[r]), s2 = ssg_row16_sum(s2v[r]);
+        if (l15 == 0) {
+          const int col = wn * WTN + j * 16 + kg * 4 + r;
+          red[(wm * 2 + 0) * BN + col] = (double)s1;
+          red[(wm * 2 + 1) * BN + col] = (double)s2;
+        }
+      }
+    } else if (want_bn) {
       // Column sums for the batch-norm statistics: fp32 sums of DEVIATIONS from a pivot shared by the 16 lanes of a row group (the
       // group's first value of the column), converted to sums of the values in fp64 once per wave and column:
       // S1 = s1 + n*c, S2 = s2 + 2*c*s1 + n*c^2 (plain fp32 sums of v and v^2 lose var = E[v^2] - mean^2 once |mean| >> std).
@@ -488,7 +530,7 @@ __global__ __launch_bounds__(256) void pack_split_k32_kernel(const float* __rest
   }
 }
 
-template <int TH, int BN, int WAVES_M, int WAVES_N, bool XF = false>
+template <int TH, int BN, int WAVES_M, int WAVES_N, bool XF = false, bool BWD = false>
 int launch(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
   constexpr int NW = WAVES_M * WAVES_N;
@@ -503,10 +545,10 @@ int launch(const ConvArgs& a0, hipStream_t st) {
   static_assert(lds_bytes <= 160 * 1024 && (NW != 4 || BN <= 32 || lds_bytes <= 80 * 1024), "LDS budget");
   constexpr int tab_bytes = XF ? 2 * SSG_K32_XF_MAXC * 4 : 0;       // scale | shift of up to SSG_K32_XF_MAXC input channels
   static_assert(lds_bytes + tab_bytes <= 160 * 1024, "LDS budget with the input-transform table");
-  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N, XF>,
+  static const hipError_t attr = hipFuncSetAttribute((const void*)conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N, XF, BWD>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes + tab_bytes);
   if (attr != hipSuccess) { ssg_set_error("conv halo k32: LDS attribute: %s", hipGetErrorString(attr)); return (int)attr; }
-  hipLaunchKernelGGL((conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N, XF>), grid, dim3(NW * 64), lds_bytes + (XF ? 2 * a.C1 * 4 : 0), st, a);
+  hipLaunchKernelGGL((conv_halo_k32_kernel<TH, BN, WAVES_M, WAVES_N, XF, BWD>), grid, dim3(NW * 64), lds_bytes + (XF ? 2 * a.C1 * 4 : 0), st, a);
   SSG_LAUNCH_CHECK();
   return SSG_OK;
 }
@@ -573,7 +615,20 @@ bool ssg_conv_halo_k32_in_affine_ok(const ConvArgs& a, int fmt) {
   return a.in_act == SSG_ACT_NONE || a.in_act == SSG_ACT_RELU || a.in_act == SSG_ACT_LRELU;
 }
 
+// backward-statistics epilogue (ssg_conv_desc.bwd_x): the three wide tiles, whole 4-channel quads everywhere
+bool ssg_conv_halo_k32_bwd_stats_ok(const ConvArgs& a, int fmt) {
+  if (fmt != 1128 && fmt != 1064 && fmt != 2064) return false;
+  if ((a.bwd_ldx & 3) || ((uintptr_t)a.bwd_x & 15) || ((uintptr_t)a.bwd_scale & 15) || ((uintptr_t)a.bwd_shift & 15) || ((uintptr_t)a.bwd_mean & 15)) return false;
+  return a.bwd_act == SSG_ACT_NONE || a.bwd_act == SSG_ACT_RELU || a.bwd_act == SSG_ACT_LRELU;
+}
+
 int ssg_conv_igemm_halo_k32_launch(const ConvArgs& a, int fmt, hipStream_t st) {
+  if (a.bwd_x) {
+    if (!a.bnpart || a.in_scale || !ssg_conv_halo_k32_bwd_stats_ok(a, fmt)) { ssg_set_error("conv halo k32: bwd_x on a launch without the backward-statistics epilogue"); return SSG_EINVAL; }
+    if (fmt == 1128) return launch<8, 128, 4, 2, false, true>(a, st);
+    if (fmt == 1064) return launch<4, 64, 2, 2, false, true>(a, st);
+    return launch<16, 64, 8, 1, false, true>(a, st);
+  }
   if (a.in_scale) {
     if (!a.in_shift || !ssg_conv_halo_k32_in_affine_ok(a, fmt)) { ssg_set_error("conv halo k32: in_scale on a launch without the fused input transform"); return SSG_EINVAL; }
     if (fmt == 1128) return launch<8, 128, 4, 2, true>(a, st);

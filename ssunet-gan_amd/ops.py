@@ -266,7 +266,7 @@ _DECLINED = object()      # _conv_launch: the library has no kernel with the fus
 
 
 def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps, n, h, w, gh, gw, oh, ow,
-                 in_s, out_s, out_oy, out_ox, out, want_bn=False, tag=None, parity_merge=False, in_affine=None):
+                 in_s, out_s, out_oy, out_ox, out, want_bn=False, tag=None, parity_merge=False, in_affine=None, bwd_stats=None):
     """Returns None, or -- with want_bn and a kernel that has the statistics epilogue -- the fp64 tensor [rows, 2, cout] of
     per-tile (sum, sum of squares) of the conv output (ssg_conv_desc.bnpart).  parity_merge: the nine taps are the four parity
     classes of a 3x3 stride-2 input gradient (ssg_conv_desc.parity_merge); returns False, with nothing launched, when the library
@@ -298,6 +298,7 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
     d.w_split = None
     d.parity_merge = 1 if parity_merge else 0
     d.in_scale = None; d.in_shift = None; d.in_act = ACT_NONE; d.in_slope = 0.0
+    d.bwd_x = None; d.bwd_ldx = 0; d.bwd_scale = None; d.bwd_shift = None; d.bwd_mean = None; d.bwd_act = ACT_NONE; d.bwd_slope = 0.0
     split = None
     if parity_merge and not (MFMA_SPLIT and kmode == 0 and call('ssg_conv2d_split_bn', C.byref(d)) == 64):
         return False
@@ -311,12 +312,23 @@ def _conv_launch(x1, x2, wpk, kp, kmode, row0, cout, bias, res, act, slope, taps
         if split is None or not call('ssg_conv2d_in_affine_ok', C.byref(d)):
             return _DECLINED
         bn = call('ssg_conv2d_split_bn', C.byref(d))      # with the transform a 16-row launch becomes a 4-row one (same pack)
+    if bwd_stats is not None:
+        # (x, stats rows [mean, invstd, scale, shift], act, slope): the launch produces d(act(bn(x))), masks it and writes the batch-norm
+        # backward sums as per-tile rows (ssg_conv_desc.bwd_x); _DECLINED, with nothing launched, where the kernel has no such epilogue
+        bx, bst, bact, bslope = bwd_stats
+        d.bwd_x = bx.data_ptr(); d.bwd_ldx = _ld(bx); d.bwd_scale = bst[2].data_ptr(); d.bwd_shift = bst[3].data_ptr()
+        d.bwd_mean = bst[0].data_ptr(); d.bwd_act = int(bact); d.bwd_slope = float(bslope)
+        if split is None or not call('ssg_conv2d_bwd_stats_ok', C.byref(d)):
+            return _DECLINED
+        want_bn = True
     part = None
     if want_bn and BN_EPILOGUE:
         rows = call('ssg_conv2d_bnpart_rows', C.byref(d))
         if rows > 0:
             part = torch.empty((rows, 2, cout), dtype=torch.float64, device=out.device)
             d.bnpart = part.data_ptr()
+    if bwd_stats is not None and part is None:
+        return _DECLINED
     ws = None
     if part is None and split is None:  # split-K (small pixel grids with a long reduction): the kernel needs a workspace
         need = call('ssg_conv2d_workspace_bytes', C.byref(d))
@@ -414,9 +426,12 @@ def _conv_fwd_impl(x1, x2, weight, bias, stride, pad, act, slope, res=None, out=
     return (out, part) if want_bn else out
 
 
-def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None, wscale=None):
+def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None, wscale=None, bwd_stats=None):
     """Input gradient for input channels [c_lo, c_hi) -> NHWC tensor [N, c_hi-c_lo, h, w].
-    `res` (same shape) is added in the epilogue: gradient accumulation without an extra pass."""
+    `res` (same shape) is added in the epilogue: gradient accumulation without an extra pass.
+    bwd_stats = (x, stats, act, slope): the gradient is that of act(bn(x)); returns (g, part) -- the MASKED gradient and the per-tile rows
+    (sum g, sum g * (x - mean)) of the batch-norm backward from the epilogue (ssg_conv_desc.bwd_x) -- or None, with nothing launched,
+    where the kernel this launch maps to has no such epilogue."""
     o, i, kh, kw = weight.shape
     n, _, oh, ow = dy.shape
     cred_pad = pad4(o)
@@ -425,8 +440,13 @@ def _conv_dgrad_impl(dy, weight, stride, pad, h, w, c_lo, c_hi, res=None, wscale
     if stride == 1:
         taps = [(ky, kx, pt - ky, pl - kx) for ky in range(kh) for kx in range(kw)]
         wpk, kp, kmode = _pack(weight, 1, taps, cred_pad, cred_pad, sigma=wscale)
-        _conv_launch(dy, None, wpk, kp, kmode, c_lo, c_hi - c_lo, None, res, ACT_NONE, 0.0, taps, n, oh, ow, h, w, h, w, 1, 1, 0, 0, dx)
+        part = _conv_launch(dy, None, wpk, kp, kmode, c_lo, c_hi - c_lo, None, res, ACT_NONE, 0.0, taps, n, oh, ow, h, w, h, w, 1, 1, 0, 0, dx,
+                            bwd_stats=bwd_stats)
+        if bwd_stats is not None:
+            return None if part is _DECLINED else (dx, part)
         return dx
+    if bwd_stats is not None:
+        return None
     if res is not None:
         raise NotImplementedError('strided dgrad with fused accumulation')
     s = stride
@@ -769,6 +789,40 @@ def _bn_bwd_body(x, y, dy, weight, stats, act, slope, group, count, want_dres, w
     if synced:
         dwb = torch.stack([local[c:2 * c], local[:c]]).float()
     return dx, dres, dwb[0], dwb[1]
+
+
+# SSG_BN_BWD_EPILOGUE=1: bn1's backward sums of a residual block from the epilogue of conv2's input gradient (ssg_conv_desc.bwd_x) instead of
+# a reduce pass over (dy1, c1).  Measured (same box, twice on two boxes): bn_bwd 14.4 -> 12.7 ms per step, and the k32 launches that carry
+# the epilogue give it back (<8,128> -1.4 %, <16,64> -3 % over all their launches): 191.9 / 191.8 vs 192.1 / 191.9 ms, 189.6 / 190.9 vs
+# 189.9 / 190.5.  Off by default.
+BN_BWD_EPILOGUE = _os.environ.get('SSG_BN_BWD_EPILOGUE', '0') == '1'
+
+
+def _bn_bwd_from_partials(x, g, part, weight, stats, group, count):
+    """Batch-norm backward whose two sums came out of the producing input-gradient launch (ssg_conv_desc.bwd_x): g is already masked, `part`
+    holds per-tile rows (sum g, sum g * (x - mean)).  Fold, scale the second sum by invstd (-> sum g * xhat), all-reduce when synchronised,
+    apply.  Returns (dx, dweight, dbias) like _bn_bwd_impl."""
+    n, c, h, w = x.shape
+    p = n * h * w
+    dev = x.device
+    synced = count is not None
+    rows = part.numel() // (2 * c)
+    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+    ws = _ws(call('ssg_bn_stats_from_partials_workspace_bytes', rows, c), dev)
+    call('ssg_bn_stats_from_partials_f32', ptr(part), rows, c, ptr(sums), float(p) if synced else 0.0, ptr(ws), stream_ptr())
+    sums[c:2 * c] *= stats[1].double()
+    local = sums.clone() if synced else sums
+    if synced:
+        _timed_all_reduce('sync_bn_bwd', sums, group)
+    dwb = torch.empty((2, c), dtype=torch.float32, device=dev)
+    dx = new_nhwc(n, c, h, w, dev)
+    with _hbm('bn_bwd', 4.0 * p * c * 3):
+        call('ssg_bn_bwd_apply_f32', ptr(x), None, ptr(g), p, c, _ld(x), 0, _ld(g),
+             ptr(stats[0]), ptr(stats[1]), ptr(weight), ptr(stats[2]), ptr(stats[3]), ptr(sums), 0.0 if synced else float(p), ACT_NONE, 0.0,
+             ptr(dx), _ld(dx), None, 0, ptr(dwb[0]), ptr(dwb[1]), stream_ptr())
+    if synced:
+        dwb = torch.stack([local[c:2 * c], local[:c]]).float()
+    return dx, dwb[0], dwb[1]
 
 
 def _relabel(t, c):

@@ -45,7 +45,7 @@ def test_ctypes_table_matches_header(pkg):
         if name in sig:
             assert len(sig[name]) == n, '%s: header has %d params, ctypes table %d' % (name, n, len(sig[name]))
     lib = pkg._lib.load()
-    assert lib.ssg_abi_version() == 8 == pkg._lib.ABI_VERSION
+    assert lib.ssg_abi_version() == 9 == pkg._lib.ABI_VERSION
     assert lib.ssg_last_error() is not None
 
 

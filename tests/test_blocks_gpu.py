@@ -132,6 +132,49 @@ def test_basic_block_bn_apply_fused_into_conv2(pkg, dev, cin, cout, h, w, nb):
     assert err.max().item() <= 1e-4 * max(1.0, o.abs().max().item()), err.max().item()
 
 
+@pytest.mark.parametrize('cin,cout,h,w,nb', [(64, 64, 48, 64, 4), (128, 128, 40, 72, 2), (64, 128, 33, 50, 3)])
+def test_basic_block_bn1_backward_sums_from_the_dgrad_epilogue(pkg, dev, cin, cout, h, w, nb):
+    """bn1's backward sums (sum g, sum g * xhat) from the epilogue of conv2's input gradient (ssg_conv_desc.bwd_x, archs.py:229-230) instead
+    of a reduce pass over (dy1, c1): the forward is untouched (same bits), every gradient agrees with the two-pass route to fp32
+    accumulation error (the sums are formed in a different order: fp32 inside a 16-lane group of the tile, fp64 beyond)."""
+    ops = pkg.ops
+    call = pkg._lib.call
+    torch.manual_seed(6)
+    m = pkg.archs.BasicBlock(cin, cout).to(dev).train()
+    x0 = torch.randn(nb, cin, h, w, device=dev)
+    dy = torch.randn(nb, cout, h, w, device=dev)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    used = []
+    real = ops._bn_bwd_from_partials
+
+    def counting(*a, **k):
+        used.append(1)
+        return real(*a, **k)
+    outs = {}
+    saved = ops.BN_BWD_EPILOGUE
+    call('ssg_conv_set_k32_mode', 2)
+    ops._bn_bwd_from_partials = counting
+    try:
+        for on in (False, True):
+            m.load_state_dict(state)
+            ops.BN_BWD_EPILOGUE = on
+            del used[:]
+            x = x0.clone().requires_grad_(True)
+            m.zero_grad(set_to_none=True)
+            y = m(x)
+            y.backward(dy)
+            outs[on] = (y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in m.parameters()], len(used))
+    finally:
+        ops._bn_bwd_from_partials = real
+        ops.BN_BWD_EPILOGUE = saved
+        call('ssg_conv_set_k32_mode', 1)
+    assert outs[True][3] == 1 and outs[False][3] == 0, (outs[True][3], outs[False][3])
+    assert torch.equal(outs[True][0], outs[False][0])
+    for a, b, what in [(outs[True][1], outs[False][1], 'dx')] + [(a, b, 'param %d' % i) for i, (a, b) in enumerate(zip(outs[True][2], outs[False][2]))]:
+        err = (a - b).abs().max().item()
+        assert err <= 2e-5 * max(1.0, b.abs().max().item()), '%s: %.3e (max %.3e)' % (what, err, b.abs().max().item())
+
+
 @pytest.mark.parametrize('tag', ['sp_a', 'sp_b'])
 def test_spade(pkg, dev, gold, tag):
     c, hw = [int(v) for v in gold[tag + '_cfg']]
