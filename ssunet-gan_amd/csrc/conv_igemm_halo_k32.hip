@@ -34,9 +34,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifdef SSG_K32_PROBE
 // diagnostic build only (tools/k32_probe.py): per workgroup s_memtime at kernel start / loop start / loop end / kernel end (+ s_memrealtime,
 // 100 MHz, at the first and last: the in-kernel clock)
-// 24 slots per workgroup: 0-3 the four stamps, 4-5 s_memrealtime, 8 + 2 * wave + {0, 1}: cycles wave `wave` spent, summed over the K-steps,
+// 32 slots per workgroup: 0-3 the four stamps, 4-5 s_memrealtime, 6-7 / 24-25 the prologue / epilogue sub-stamps, 8 + 2 * wave + {0, 1}: cycles wave `wave` spent, summed over the K-steps,
 // (0) on its own vmcnt / lgkmcnt waits at the top of a step and (1) inside the step's s_barrier (waiting for the slowest wave)
-constexpr int SSG_PROBE_SLOTS = 24;
+constexpr int SSG_PROBE_SLOTS = 32;
 __device__ unsigned long long* ssg_probe_buf_k32 = nullptr;
 #define SSG_STAMP(i) do { if (ssg_probe_buf_k32 && tid == 0) { ssg_probe_buf_k32[SSG_PROBE_SLOTS * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); \
                                                             if ((i) == 0 || (i) == 3) ssg_probe_buf_k32[SSG_PROBE_SLOTS * blockIdx.x + 4 + ((i) == 3)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l15 = lane & 15, kg = lane >> 4;
 
+  SSG_STAMP(7);                                            // (probe build) kernel entry; stamp 0 follows the address set-up
   int bid = blockIdx.x;
   if (a.xcd_swizzle) {
     const int per = (int)gridDim.x >> 3;
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     __syncthreads();
   }
   wait_vmcnt<2 * B_PC>();
+  SSG_STAMP(6);                                            // (probe build) chunk 0's pixels have landed
   convert_px(0);
   write_px();
   SSG_STAMP(1);
@@ -391,6 +393,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     }
   }
 
+  SSG_STAMP(24);                                           // (probe build) the non-finite check is done
   // ---- epilogue.  acc[i][j][r]: pixel p = wm*64 + i*16 + l15, output channel n0 + wn*WTN + j*16 + kg*4 + r.
   const bool want_bn = a.bnpart != nullptr;
   if (want_bn) __syncthreads();                          // the image and the ring are dead for every wave: LDS becomes scratch
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 8) ? 
     }
   }
 #ifdef SSG_K32_PROBE
+  SSG_STAMP(25);                                           // every store has been issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the output stores have left
   SSG_STAMP(3);
 #endif

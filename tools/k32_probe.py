@@ -14,7 +14,7 @@ from ssunet_gan_amd import ops, _lib
 from ssunet_gan_amd._lib import ACT_NONE
 dev = 'cuda'
 lib = _lib.load()
-SLOTS = 24
+SLOTS = 32
 probe = torch.zeros(SLOTS * 65536, dtype=torch.int64, device=dev)
 assert lib.ssg_debug_set_probe_buffer_k32(C.c_void_p(probe.data_ptr())) == 0
 ops.MFMA_SPLIT = True
@@ -37,6 +37,7 @@ for (ci, co, hw) in [(64, 64, 512), (192, 64, 512), (128, 128, 256), (512, 512, 
     print('cin%d cout%d %dx%d: %d workgroups; per tile (median cycles): prologue %.0f, main loop %.0f (%.0f per step; MFMA issue alone: 3072), epilogue + store drain %.0f, '
           'total %.0f; in-kernel clock %.2f GHz (s_memtime / s_memrealtime)' % (ci, co, hw, hw, p.shape[0], d(0, 1), d(1, 2), d(1, 2) / (ci // 32 * 9), d(2, 3), d(0, 3), clk), flush=True)
     print('    prologue split: entry -> loads issued %.0f, -> pixels landed %.0f, -> split + written %.0f' % (d(7, 0), d(0, 6), d(6, 1)), flush=True)
+    print('    epilogue split: loop end -> non-finite check done %.0f, -> stores issued %.0f, -> stores acknowledged %.0f' % (d(2, 24), d(24, 25), d(25, 3)), flush=True)
     nst = ci // 32 * 9
     nw = 8 if (p[:, 8 + 2 * 7] + p[:, 9 + 2 * 7]).median().item() > 0 else 4
     own = [p[:, 8 + 2 * w].median().item() / nst for w in range(nw)]
