@@ -135,8 +135,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_x3_kernel(const ConvArg
 #define SSG_X3_TERM(A, B)                                                                           \
   _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[j], acc[j], 0, 0, 0);
-    SSG_X3_TERM(a3, b1) SSG_X3_TERM(a2, b2) SSG_X3_TERM(a1, b3)
+#ifndef SSG_X3_DYNPRIO
+#define SSG_X3_DYNPRIO 1                                   // 1: wave priority falls through the step's six terms (as the k32 kernels).  Same-box A/B: +3-4 % here (stride-2 / 1x1 forward); the same in wgrad_dma_x3 lost 2-3 % and in the merged-parity halo kernel changed nothing: not there
+#endif
+    if (SSG_X3_DYNPRIO) __builtin_amdgcn_s_setprio(3);
+    SSG_X3_TERM(a3, b1) SSG_X3_TERM(a2, b2)
+    if (SSG_X3_DYNPRIO) __builtin_amdgcn_s_setprio(2);
+    SSG_X3_TERM(a1, b3)
+    if (SSG_X3_DYNPRIO) __builtin_amdgcn_s_setprio(1);
     SSG_X3_TERM(a2, b1) SSG_X3_TERM(a1, b2)
+    if (SSG_X3_DYNPRIO) __builtin_amdgcn_s_setprio(0);
     SSG_X3_TERM(a1, b1)
 #undef SSG_X3_TERM
   }
