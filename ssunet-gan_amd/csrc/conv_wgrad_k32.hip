@@ -76,63 +76,62 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
   const auto x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, (int)(npix * (unsigned)xld * 4u), 0x00020000);
   const auto d_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, (int)((unsigned)a.N * (unsigned)a.GH * (unsigned)a.GW * (unsigned)a.ldd * 4u), 0x00020000);
 
-  // ---- staging items: threads 0..271 one (window pixel, 8-channel chunk) of the new x row, threads 256..511 one (pixel, chunk) of the dy row
-  const bool has_x = tid < 34 * 8, has_d = tid >= 256;
-  const int xi_px = tid >> 3, xi_c = tid & 7;
-  const int di_px = (tid - 256) >> 3, di_c = tid & 7;
-  const int x_dst = xi_px * 128 + ((xi_c ^ sw(xi_px)) << 4);
-  const int d_dst = di_px * 128 + ((di_c ^ sw(di_px)) << 4);
+  // ---- staging items, 16-byte pieces in lane order: a wave instruction covers 4 pixels x the 256 bytes of their 64 channels (whole lines;
+  // the first form -- a thread = one pixel's 8-channel chunk as two loads 16 bytes apart -- touched every line from two instructions, and
+  // had threads 0..271 stage x, 256..511 dy: wave 4 did both).  Piece t of the new x row = (window pixel t >> 4, quarter t & 15) for every
+  // thread, pieces 512..543 (window pixels 32, 33) once more for threads 0..31; piece t of the dy row for every thread.
+  const int s_px = tid >> 4, s_q = tid & 15;
+  const bool has_x2 = tid < 32;
+  const int x_dst = s_px * 128 + (((s_q >> 1) ^ sw(s_px)) << 4) + (s_q & 1) * 8;
+  const int x_dst2 = (32 + s_px) * 128 + (((s_q >> 1) ^ sw(32 + s_px)) << 4) + (s_q & 1) * 8;      // threads 0..31: s_px = 0, 1
+  const int d_dst = x_dst;                               // same (pixel, quarter) position in the dy slot
 
-  struct Raw { u32x4 lo, hi; };
+  struct RawX { u32x4 a, b; };
+  struct RawD { u32x4 a; };
   float* const xtab = (float*)(lds + XIMG + DIMG);        // XF: scale[64] | shift[64] of this workgroup's input channels
   if constexpr (XF) {                                    // C2 == 0 (ssg_conv2d_wgrad_in_affine_ok); visible after the first segment's barrier
     if (tid < 128) xtab[tid] = tid < 64 ? a.in_scale[c0 + tid] : a.in_shift[c0 + tid - 64];
   }
-  auto load_x = [&](int n, int row, int gx0) -> Raw {    // window row `row` (may be -1 or H: zeros), columns gx0 - 1 .. gx0 + 32
-    const int ix = gx0 - 1 + xi_px;
-    const bool ok = has_x && (unsigned)row < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    const unsigned vo = ok ? (unsigned)((n * a.H + row) * a.W + ix) * (unsigned)xld * 4u + (unsigned)(xc0 + 8 * xi_c) * 4u : OOB;
-    Raw r;
-    r.lo = __builtin_amdgcn_raw_buffer_load_b128(x_rs, vo, 0, 0);
-    r.hi = __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? vo + 16u : OOB, 0, 0);
+  auto x_inside = [&](int row, int gx0, int px) -> bool {        // is window pixel px of row `row` inside the image
+    return (unsigned)row < (unsigned)a.H && (unsigned)(gx0 - 1 + px) < (unsigned)a.W;
+  };
+  auto load_x = [&](int n, int row, int gx0) -> RawX {   // window row `row` (may be -1 or H: zeros), columns gx0 - 1 .. gx0 + 32
+    const unsigned rowbase = (unsigned)((n * a.H + row) * a.W + gx0 - 1);
+    const unsigned cho = (unsigned)(xc0 + 4 * s_q) * 4u;
+    const unsigned vo = x_inside(row, gx0, s_px) ? (rowbase + (unsigned)s_px) * (unsigned)xld * 4u + cho : OOB;
+    const unsigned vo2 = (has_x2 && x_inside(row, gx0, 32 + s_px)) ? (rowbase + 32u + (unsigned)s_px) * (unsigned)xld * 4u + cho : OOB;
+    RawX r;
+    r.a = __builtin_amdgcn_raw_buffer_load_b128(x_rs, vo, 0, 0);
+    r.b = __builtin_amdgcn_raw_buffer_load_b128(x_rs, vo2, 0, 0);
     return r;
   };
-  auto load_d = [&](int n, int gy, int gx0) -> Raw {
-    const int gx = gx0 + di_px;
-    const bool ok = has_d && gx < a.GW;
-    const unsigned vo = ok ? (unsigned)((n * a.GH + gy) * a.GW + gx) * (unsigned)a.ldd * 4u + (unsigned)(n0 + 8 * di_c) * 4u : OOB;
-    Raw r;
-    r.lo = __builtin_amdgcn_raw_buffer_load_b128(d_rs, vo, 0, 0);
-    r.hi = __builtin_amdgcn_raw_buffer_load_b128(d_rs, ok ? vo + 16u : OOB, 0, 0);
+  auto load_d = [&](int n, int gy, int gx0) -> RawD {
+    const int gx = gx0 + s_px;
+    const unsigned vo = gx < a.GW ? (unsigned)((n * a.GH + gy) * a.GW + gx) * (unsigned)a.ldd * 4u + (unsigned)(n0 + 4 * s_q) * 4u : OOB;
+    RawD r;
+    r.a = __builtin_amdgcn_raw_buffer_load_b128(d_rs, vo, 0, 0);
     return r;
   };
-  auto x_inside = [&](int row, int gx0) -> bool {        // XF: is this thread's window pixel of row `row` inside the image
-    return (unsigned)row < (unsigned)a.H && (unsigned)(gx0 - 1 + xi_px) < (unsigned)a.W;
+  auto put = [&](unsigned char* base, int plane_bytes, f32x4 v) {
+    bf16x4 p1, p2, p3;
+    split3_4(v, p1, p2, p3);
+    *(bf16x4*)base = p1; *(bf16x4*)(base + plane_bytes) = p2; *(bf16x4*)(base + 2 * plane_bytes) = p3;
   };
-  auto store_x = [&](const Raw& r, int slot, bool inside) {
-    if (has_x) {
-      bf16x8 p1, p2, p3;
-      f32x4 lo = __builtin_bit_cast(f32x4, r.lo), hi = __builtin_bit_cast(f32x4, r.hi);
-      if constexpr (XF) {
-        const f32x4 s0 = *(const f32x4*)(xtab + 8 * xi_c), s1 = *(const f32x4*)(xtab + 8 * xi_c + 4);
-        const f32x4 h0 = *(const f32x4*)(xtab + 64 + 8 * xi_c), h1 = *(const f32x4*)(xtab + 64 + 8 * xi_c + 4);
-        lo = lo * s0 + h0; hi = hi * s1 + h1;                             // bn_apply_kernel's expression
+  auto xform = [&](f32x4 v, bool inside) -> f32x4 {
+    if constexpr (XF) {
+      v = v * *(const f32x4*)(xtab + 4 * s_q) + *(const f32x4*)(xtab + 64 + 4 * s_q);      // bn_apply_kernel's expression
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { lo[e] = ssg_act(lo[e], a.in_act, a.in_slope); hi[e] = ssg_act(hi[e], a.in_act, a.in_slope); }
-        if (!inside) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = lo; }
-      }
-      split3(lo, hi, p1, p2, p3);
-      unsigned char* d = ximg + slot * XSLOT + x_dst;
-      *(bf16x8*)d = p1; *(bf16x8*)(d + XPLANE) = p2; *(bf16x8*)(d + 2 * XPLANE) = p3;
+      for (int e = 0; e < 4; ++e) v[e] = ssg_act(v[e], a.in_act, a.in_slope);
+      if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    return v;
   };
-  auto store_d = [&](const Raw& r, int slot) {
-    if (has_d) {
-      bf16x8 p1, p2, p3;
-      split3(__builtin_bit_cast(f32x4, r.lo), __builtin_bit_cast(f32x4, r.hi), p1, p2, p3);
-      unsigned char* d = dimg + slot * DSLOT + d_dst;
-      *(bf16x8*)d = p1; *(bf16x8*)(d + DPLANE) = p2; *(bf16x8*)(d + 2 * DPLANE) = p3;
-    }
+  auto store_x = [&](const RawX& r, int slot, int row, int gx0) {
+    put(ximg + slot * XSLOT + x_dst, XPLANE, xform(__builtin_bit_cast(f32x4, r.a), XF ? x_inside(row, gx0, s_px) : true));
+    if (has_x2) put(ximg + slot * XSLOT + x_dst2, XPLANE, xform(__builtin_bit_cast(f32x4, r.b), XF ? x_inside(row, gx0, 32 + s_px) : true));
+  };
+  auto store_d = [&](const RawD& r, int slot) {
+    put(dimg + slot * DSLOT + d_dst, DPLANE, __builtin_bit_cast(f32x4, r.a));
   };
 
   // ---- transposed-read addresses.  Operand k-group g covers pixels 8g .. 8g+7 of the step; lane 4q+pp of the group supplies pixel
@@ -184,9 +183,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
     __builtin_amdgcn_s_barrier();                        // the previous segment's last reads are done
     asm volatile("" ::: "memory");
     {
-      const Raw r0 = load_x(n, ga - 1, gx0), r1 = load_x(n, ga, gx0), r2 = load_x(n, ga + 1, gx0), r3 = load_d(n, ga, gx0);   // all in flight together
-      store_x(r0, (ga + 0) & 3, XF ? x_inside(ga - 1, gx0) : true); store_x(r1, (ga + 1) & 3, XF ? x_inside(ga, gx0) : true);
-      store_x(r2, (ga + 2) & 3, XF ? x_inside(ga + 1, gx0) : true); store_d(r3, ga & 1);
+      const RawX r0 = load_x(n, ga - 1, gx0), r1 = load_x(n, ga, gx0), r2 = load_x(n, ga + 1, gx0);
+      const RawD r3 = load_d(n, ga, gx0);                // all in flight together
+      store_x(r0, (ga + 0) & 3, ga - 1, gx0); store_x(r1, (ga + 1) & 3, ga, gx0);
+      store_x(r2, (ga + 2) & 3, ga + 1, gx0); store_d(r3, ga & 1);
     }
 
     for (int gy = ga; gy < gb; ++gy) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const bool more = gy + 1 < gb;
-      Raw nx, nd;
+      RawX nx; RawD nd;
 #ifndef SSG_WK32_LOAD_MID
 #define SSG_WK32_LOAD_MID 0                                // 1: the next rows' loads go out after the first tap row's MFMAs instead of behind the barrier (A/B build switch)
 #endif
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_k32_kernel(const WgArgs a) {
       if (SSG_WK32_DYNPRIO) __builtin_amdgcn_s_setprio(0);
       if (more) {
         __builtin_amdgcn_sched_barrier(0);
-        store_x(nx, (gy + 3) & 3, XF ? x_inside(gy + 2, gx0) : true);      // row gy + 2
+        store_x(nx, (gy + 3) & 3, gy + 2, gx0);         // row gy + 2
         store_d(nd, (gy + 1) & 1);
       }
       if (FLUSH > 0 && ++since == FLUSH) {
